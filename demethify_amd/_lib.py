@@ -1,0 +1,90 @@
+"""ctypes binding of libdemethify_hip.so (C-ABI declared in include/demethify_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or no gfx950 device
+is visible, every solver call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libdemethify_hip.so"
+
+DMF_OK = 0
+DMF_PTR_DEVICE = 1
+DMF_COUNTS_F64 = 2
+DMF_MODE_PARTIAL = 0
+DMF_MODE_UNSUPERVISED = 1
+KERNEL_ROWPASS, KERNEL_GRAM, KERNEL_ALPHA, KERNEL_COST = 0, 1, 2, 3
+KERNEL_FAMILIES = ("rowpass", "gram", "alpha", "cost")
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_dbl_p = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); every symbol include/demethify_hip.h declares
+SIGNATURES = {
+    "dmf_status_string": (C.c_char_p, [C.c_int]),
+    "dmf_last_error": (C.c_char_p, []),
+    "dmf_abi_version": (C.c_int, []),
+    "dmf_context_create": (C.c_int, [C.c_int, _p, C.POINTER(_p)]),
+    "dmf_context_destroy": (C.c_int, [_p]),
+    "dmf_context_synchronize": (C.c_int, [_p]),
+    "dmf_context_set_profiling": (C.c_int, [_p, C.c_int]),
+    "dmf_context_kernel_time": (C.c_int, [_p, C.c_int, _dbl_p, C.POINTER(_i64)]),
+    "dmf_context_reset_kernel_time": (C.c_int, [_p]),
+    "dmf_context_set_generic": (C.c_int, [_p, C.c_int]),
+    "dmf_problem_create": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, C.c_int, C.POINTER(_p)]),
+    "dmf_problem_gather": (C.c_int, [_p, _p, _p, _i64, C.POINTER(_p)]),
+    "dmf_problem_destroy": (C.c_int, [_p]),
+    "dmf_problem_shape": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "dmf_cost": (C.c_int, [_p, _p, _p, _i64, _p, C.c_int, _dbl_p]),
+    "dmf_project_simplex": (C.c_int, [_p, _p, _i64, _i64, C.c_double, C.c_int, _p]),
+    "dmf_update_u": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, C.c_int, C.c_int, _dbl_p, _p, _p]),
+    "dmf_update_alpha": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, C.c_int, _dbl_p, _p, _p]),
+    "dmf_solver_create": (C.c_int, [_p, _p, _p, _p, _i64, C.c_int, C.c_int, C.POINTER(_p)]),
+    "dmf_solver_step": (C.c_int, [_p, _i64, _i64, C.c_double, C.POINTER(_i64), C.POINTER(C.c_int)]),
+    "dmf_solver_get": (C.c_int, [_p, C.c_int, _p, _p, _dbl_p, C.POINTER(_i64)]),
+    "dmf_solver_destroy": (C.c_int, [_p]),
+    "dmf_solve": (C.c_int, [_p, _p, _p, _p, _i64, C.c_int, _i64, _i64, C.c_double, C.c_int, _p, _p,
+                            _dbl_p, C.POINTER(_i64)]),
+}
+
+_lib = None
+
+
+class DemethifyHipError(RuntimeError):
+    """A C-ABI call returned a non-zero dmf_status."""
+
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        msg = f"{where}: status {status}"
+        if detail:
+            msg += f" ({detail})"
+        super().__init__(msg)
+
+
+def load():
+    """Load the shared library (once) and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m demethify_amd._build` "
+            "(there is no CPU fallback)")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int, where: str):
+    if status != DMF_OK:
+        lib = load()
+        text = lib.dmf_status_string(status).decode()
+        err = lib.dmf_last_error().decode()
+        raise DemethifyHipError(status, where, f"{text}; {err}" if err else text)

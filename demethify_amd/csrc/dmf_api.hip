@@ -1,0 +1,770 @@
+// C-ABI of libdemethify_hip.so: handles, memory ownership, the outer-loop driver and the
+// per-family HIP-event timers.  See include/demethify_hip.h for the contract.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/demethify_hip.h"
+#include "dmf_internal.h"
+
+using dmf::SolverState;
+
+namespace {
+
+thread_local char g_last_error[512] = "";
+
+int hip_fail(hipError_t e, const char* what, int line) {
+    snprintf(g_last_error, sizeof(g_last_error), "%s failed at dmf_api.hip:%d: %s", what, line,
+             hipGetErrorString(e));
+    return DMF_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                                                   \
+    do {                                                                \
+        hipError_t e_ = (expr);                                         \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr, __LINE__);     \
+    } while (0)
+
+#define DMF_TRY(expr)                 \
+    do {                              \
+        int s_ = (expr);              \
+        if (s_ != DMF_OK) return s_;  \
+    } while (0)
+
+constexpr int kEventPool = 2048;
+
+struct FamilyClock {
+    std::vector<hipEvent_t> start, stop;
+    int used = 0;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+}  // namespace
+
+struct dmf_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    bool force_generic = false;
+    double* scratch = nullptr;  // 4096 doubles of reduction scratch
+    FamilyClock clocks[DMF_KERNEL_FAMILIES];
+};
+
+struct dmf_problem {
+    dmf_context* ctx = nullptr;
+    int64_t N = 0, S = 0, n_c = 0;
+    double *V = nullptr, *D = nullptr, *Rt = nullptr;
+    bool own_V = false, own_D = false, own_Rt = false;
+    double* consts = nullptr;    // device {dsq, ||Rt||^2, dmax}
+    double h_consts[3] = {0, 0, 0};
+    double* gb_known = nullptr;  // [(n_c+1)(n_c+2)/2][S]
+};
+
+struct dmf_solver {
+    dmf_context* ctx = nullptr;
+    const dmf_problem* p = nullptr;
+    int64_t n_u = 0;
+    int mode = 0;
+    bool use_gram_u = true;
+    double *u = nullptr, *u_prev = nullptr, *u_next = nullptr;
+    double *alpha = nullptr, *alpha_prev = nullptr;
+    double* gb = nullptr;
+    double* slab = nullptr;
+    int64_t slab_doubles = 0;
+    double* partials = nullptr;
+    SolverState* state = nullptr;
+    SolverState* h_state = nullptr;  // pinned
+    short *job_k = nullptr, *job_l = nullptr;
+    int* job_dst = nullptr;
+    int n_jobs = 0;
+};
+
+namespace {
+
+int clock_drain(dmf_context* ctx, FamilyClock& c) {
+    if (c.used == 0) return DMF_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < c.used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c.start[i], c.stop[i]));
+        c.total_ms += ms;
+    }
+    c.launches += c.used;
+    c.used = 0;
+    return DMF_OK;
+}
+
+// Brackets one launch (or a fixed group of launches) of a kernel family with HIP events on
+// the context's stream when profiling is enabled.
+struct FamilyScope {
+    dmf_context* ctx;
+    FamilyClock* c = nullptr;
+    int slot = -1;
+    FamilyScope(dmf_context* ctx_, int family) : ctx(ctx_) {
+        if (!ctx->profiling) return;
+        c = &ctx->clocks[family];
+        if (c->start.empty()) {
+            c->start.resize(kEventPool);
+            c->stop.resize(kEventPool);
+            for (int i = 0; i < kEventPool; ++i) {
+                hipEventCreate(&c->start[i]);
+                hipEventCreate(&c->stop[i]);
+            }
+        }
+        if (c->used == kEventPool) clock_drain(ctx, *c);
+        slot = c->used++;
+        hipEventRecord(c->start[slot], ctx->stream);
+    }
+    ~FamilyScope() {
+        if (c != nullptr) hipEventRecord(c->stop[slot], ctx->stream);
+    }
+};
+
+int import_array(dmf_context* ctx, const void* src, size_t bytes, int flags, void** dst, bool* owned) {
+    if (bytes == 0) {
+        *dst = nullptr;
+        *owned = false;
+        return DMF_OK;
+    }
+    if (flags & DMF_PTR_DEVICE) {
+        *dst = const_cast<void*>(src);
+        *owned = false;
+        return DMF_OK;
+    }
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    hipError_t e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        hipFree(d);
+        return hip_fail(e, "hipMemcpyAsync(H2D)", __LINE__);
+    }
+    *dst = d;
+    *owned = true;
+    return DMF_OK;
+}
+
+int export_array(dmf_context* ctx, const void* dev_src, size_t bytes, int flags, void* dst) {
+    if (bytes == 0 || dst == nullptr) return DMF_OK;
+    const hipMemcpyKind kind = (flags & DMF_PTR_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    HIP_TRY(hipMemcpyAsync(dst, dev_src, bytes, kind, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DMF_OK;
+}
+
+// Builds the per-problem constants: max(D)^2, ||Rt||_F^2 and the known block of the packed Gram.
+int problem_finalize(dmf_problem* p) {
+    dmf_context* ctx = p->ctx;
+    const int64_t N = p->N, S = p->S, n_c = p->n_c;
+    HIP_TRY(hipMalloc((void**)&p->consts, 3 * sizeof(double)));
+    HIP_TRY(dmf::launch_max_f64(p->D, N * S, ctx->scratch, p->consts + 2, ctx->stream));
+    if (n_c > 0) {
+        HIP_TRY(dmf::launch_sumsq_f64(p->Rt, N * n_c, ctx->scratch + 1024, p->consts + 1, nullptr, ctx->stream));
+    } else {
+        HIP_TRY(hipMemsetAsync(p->consts + 1, 0, sizeof(double), ctx->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(p->h_consts, p->consts, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    p->h_consts[0] = p->h_consts[2] * p->h_consts[2];  // d = max(D)**2, deconvolution.py:197
+    HIP_TRY(hipMemcpyAsync(p->consts, p->h_consts, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!std::isfinite(p->h_consts[2]) || !std::isfinite(p->h_consts[1])) return DMF_ERR_NONFINITE;
+
+    // known block: packed triangle over the extended indices (Rt_0..Rt_{n_c-1}, v)
+    const int ext = (int)n_c + 1;
+    const int n_jobs = ext * (ext + 1) / 2;
+    std::vector<short> hk(n_jobs), hl(n_jobs);
+    std::vector<int> hd(n_jobs);
+    int a = 0;
+    for (int l = 0; l < ext; ++l)
+        for (int k = 0; k <= l; ++k, ++a) {
+            hk[a] = (short)k;
+            hl[a] = (short)l;
+            hd[a] = dmf::tri(k, l);
+        }
+    short *dk = nullptr, *dl = nullptr;
+    int* dd = nullptr;
+    double* slab = nullptr;
+    const int64_t slab_doubles = dmf::gram_slab_doubles(N, (int)S, n_jobs);
+    HIP_TRY(hipMalloc((void**)&p->gb_known, (size_t)n_jobs * S * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&dk, n_jobs * sizeof(short)));
+    HIP_TRY(hipMalloc((void**)&dl, n_jobs * sizeof(short)));
+    HIP_TRY(hipMalloc((void**)&dd, n_jobs * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&slab, (size_t)slab_doubles * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(dk, hk.data(), n_jobs * sizeof(short), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dl, hl.data(), n_jobs * sizeof(short), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dd, hd.data(), n_jobs * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    dmf::GramJobTable jobs{dk, dl, dd, n_jobs};
+    hipError_t e = dmf::launch_gram(p->V, p->D, p->Rt, nullptr, N, (int)S, (int)n_c, 0, jobs, slab,
+                                    slab_doubles, p->gb_known, nullptr, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(dk);
+    hipFree(dl);
+    hipFree(dd);
+    hipFree(slab);
+    if (e != hipSuccess) return hip_fail(e, "launch_gram(known block)", __LINE__);
+    return DMF_OK;
+}
+
+int check_ctx(dmf_context* ctx) {
+    if (ctx == nullptr) return DMF_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return DMF_OK;
+}
+
+int enqueue_u_phase(dmf_solver* s, int n_iter2) {
+    dmf_context* ctx = s->ctx;
+    const dmf_problem* p = s->p;
+    FamilyScope scope(ctx, DMF_KERNEL_ROWPASS);
+    if (s->use_gram_u) {
+        HIP_TRY(dmf::launch_u_phase_gram(p->V, p->D, p->Rt, s->alpha, s->u, s->u_prev, s->state, p->N,
+                                         (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
+    } else {
+        for (int t = 0; t < n_iter2; ++t) {
+            HIP_TRY(dmf::launch_u_step_direct(p->V, p->D, p->Rt, s->alpha, s->u, s->u_prev, s->u_next,
+                                              s->state, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, t,
+                                              s->mode, ctx->stream));
+            double* old_prev = s->u_prev;
+            s->u_prev = s->u;
+            s->u = s->u_next;
+            s->u_next = old_prev;
+        }
+    }
+    return DMF_OK;
+}
+
+int enqueue_gram(dmf_solver* s) {
+    dmf_context* ctx = s->ctx;
+    const dmf_problem* p = s->p;
+    FamilyScope scope(ctx, DMF_KERNEL_GRAM);
+    dmf::GramJobTable jobs{s->job_k, s->job_l, s->job_dst, s->n_jobs};
+    HIP_TRY(dmf::launch_gram(p->V, p->D, p->Rt, s->u, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, jobs,
+                             s->slab, s->slab_doubles, s->gb, &s->state->done, ctx->stream));
+    return DMF_OK;
+}
+
+int enqueue_alpha_phase(dmf_solver* s, int n_iter2) {
+    dmf_context* ctx = s->ctx;
+    const dmf_problem* p = s->p;
+    FamilyScope scope(ctx, DMF_KERNEL_ALPHA);
+    HIP_TRY(dmf::launch_alpha_phase(s->gb, s->alpha, s->alpha_prev, s->state, (int)p->S, (int)p->n_c,
+                                    (int)s->n_u, n_iter2, s->partials, ctx->stream));
+    return DMF_OK;
+}
+
+int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
+    dmf_context* ctx = s->ctx;
+    const dmf_problem* p = s->p;
+    DMF_TRY(enqueue_u_phase(s, n_iter2));
+    HIP_TRY(dmf::launch_sumsq_f64(s->u, p->N * s->n_u, ctx->scratch, &s->state->u_norm2, &s->state->done,
+                                  ctx->stream));
+    HIP_TRY(dmf::launch_set_lh(s->state, ctx->stream));
+    DMF_TRY(enqueue_gram(s));
+    DMF_TRY(enqueue_alpha_phase(s, n_iter2));
+    return DMF_OK;
+}
+
+int fetch_state(dmf_solver* s) {
+    HIP_TRY(hipMemcpyAsync(s->h_state, s->state, sizeof(SolverState), hipMemcpyDeviceToHost, s->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    return DMF_OK;
+}
+
+int push_state(dmf_solver* s) {
+    HIP_TRY(hipMemcpyAsync(s->state, s->h_state, sizeof(SolverState), hipMemcpyHostToDevice, s->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    return DMF_OK;
+}
+
+double advance_momentum(double a, int64_t n) {
+    for (int64_t t = 0; t < n; ++t) a = (1.0 + std::sqrt(1.0 + 4.0 * a * a)) / 2.0;
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dmf_status_string(int status) {
+    switch (status) {
+        case DMF_OK: return "ok";
+        case DMF_ERR_BAD_ARG: return "bad argument";
+        case DMF_ERR_BAD_SHAPE: return "shape mismatch";
+        case DMF_ERR_HIP: return "HIP runtime error";
+        case DMF_ERR_NONFINITE: return "non-finite input";
+        case DMF_ERR_UNSUPPORTED: return "unsupported size";
+        case DMF_ERR_NO_DEVICE: return "no gfx950 device";
+        default: return "unknown status";
+    }
+}
+
+const char* dmf_last_error(void) { return g_last_error; }
+
+int dmf_abi_version(void) { return 1; }
+
+int dmf_context_create(int device, void* stream, dmf_context** out) {
+    if (out == nullptr) return DMF_ERR_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return DMF_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return DMF_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_last_error, sizeof(g_last_error), "device %d is %s, this library is built for gfx950",
+                 device, prop.gcnArchName);
+        return DMF_ERR_NO_DEVICE;
+    }
+    dmf_context* ctx = new (std::nothrow) dmf_context();
+    if (ctx == nullptr) return DMF_ERR_BAD_ARG;
+    ctx->device = device;
+    if (stream != nullptr) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return hip_fail(e, "hipStreamCreate", __LINE__);
+        }
+        ctx->own_stream = true;
+    }
+    hipError_t e = hipMalloc((void**)&ctx->scratch, 4096 * sizeof(double));
+    if (e != hipSuccess) {
+        if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return hip_fail(e, "hipMalloc(scratch)", __LINE__);
+    }
+    *out = ctx;
+    return DMF_OK;
+}
+
+int dmf_context_destroy(dmf_context* ctx) {
+    if (ctx == nullptr) return DMF_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& c : ctx->clocks) {
+        for (auto ev : c.start) hipEventDestroy(ev);
+        for (auto ev : c.stop) hipEventDestroy(ev);
+    }
+    hipFree(ctx->scratch);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return DMF_OK;
+}
+
+int dmf_context_synchronize(dmf_context* ctx) {
+    DMF_TRY(check_ctx(ctx));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DMF_OK;
+}
+
+int dmf_context_set_profiling(dmf_context* ctx, int enabled) {
+    DMF_TRY(check_ctx(ctx));
+    if (!enabled)
+        for (auto& c : ctx->clocks) DMF_TRY(clock_drain(ctx, c));
+    ctx->profiling = enabled != 0;
+    return DMF_OK;
+}
+
+int dmf_context_kernel_time(dmf_context* ctx, int family, double* total_ms, int64_t* launches) {
+    DMF_TRY(check_ctx(ctx));
+    if (family < 0 || family >= DMF_KERNEL_FAMILIES) return DMF_ERR_BAD_ARG;
+    FamilyClock& c = ctx->clocks[family];
+    DMF_TRY(clock_drain(ctx, c));
+    if (total_ms) *total_ms = c.total_ms;
+    if (launches) *launches = c.launches;
+    return DMF_OK;
+}
+
+int dmf_context_reset_kernel_time(dmf_context* ctx) {
+    DMF_TRY(check_ctx(ctx));
+    for (auto& c : ctx->clocks) {
+        DMF_TRY(clock_drain(ctx, c));
+        c.total_ms = 0.0;
+        c.launches = 0;
+    }
+    return DMF_OK;
+}
+
+int dmf_context_set_generic(dmf_context* ctx, int enabled) {
+    if (ctx == nullptr) return DMF_ERR_BAD_ARG;
+    ctx->force_generic = enabled != 0;
+    return DMF_OK;
+}
+
+// ------------------------------------------------------------------------------- problem
+int dmf_problem_create(dmf_context* ctx, int64_t N, int64_t S, int64_t n_c, const double* V,
+                       const void* counts, const double* Rt, int flags, dmf_problem** out) {
+    DMF_TRY(check_ctx(ctx));
+    if (out == nullptr) return DMF_ERR_BAD_ARG;
+    *out = nullptr;
+    if (N <= 0 || S <= 0 || n_c < 0 || V == nullptr || counts == nullptr) return DMF_ERR_BAD_ARG;
+    if (n_c > 0 && Rt == nullptr) return DMF_ERR_BAD_ARG;
+    if (n_c > dmf::kMaxK || S > (1 << 24)) return DMF_ERR_UNSUPPORTED;
+    dmf_problem* p = new (std::nothrow) dmf_problem();
+    if (p == nullptr) return DMF_ERR_BAD_ARG;
+    p->ctx = ctx;
+    p->N = N;
+    p->S = S;
+    p->n_c = n_c;
+    int st = import_array(ctx, V, (size_t)N * S * sizeof(double), flags, (void**)&p->V, &p->own_V);
+    if (st == DMF_OK) {
+        if (flags & DMF_COUNTS_F64) {
+            st = import_array(ctx, counts, (size_t)N * S * sizeof(double), flags, (void**)&p->D, &p->own_D);
+        } else {
+            void* raw = nullptr;
+            bool own_raw = false;
+            st = import_array(ctx, counts, (size_t)N * S * sizeof(long long), flags, &raw, &own_raw);
+            if (st == DMF_OK) {
+                hipError_t e = hipMalloc((void**)&p->D, (size_t)N * S * sizeof(double));
+                if (e == hipSuccess) {
+                    p->own_D = true;
+                    e = dmf::launch_convert_counts((const long long*)raw, p->D, N * S, ctx->stream);
+                }
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (own_raw) hipFree(raw);
+                if (e != hipSuccess) st = hip_fail(e, "count conversion", __LINE__);
+            }
+        }
+    }
+    if (st == DMF_OK)
+        st = import_array(ctx, Rt, (size_t)N * n_c * sizeof(double), flags, (void**)&p->Rt, &p->own_Rt);
+    if (st == DMF_OK) st = problem_finalize(p);
+    if (st != DMF_OK) {
+        dmf_problem_destroy(p);
+        return st;
+    }
+    *out = p;
+    return DMF_OK;
+}
+
+int dmf_problem_gather(dmf_context* ctx, const dmf_problem* src, const int64_t* idx, int64_t n_idx,
+                       dmf_problem** out) {
+    DMF_TRY(check_ctx(ctx));
+    if (src == nullptr || idx == nullptr || out == nullptr || n_idx <= 0) return DMF_ERR_BAD_ARG;
+    *out = nullptr;
+    for (int64_t r = 0; r < n_idx; ++r)
+        if (idx[r] < 0 || idx[r] >= src->N) return DMF_ERR_BAD_ARG;
+    dmf_problem* p = new (std::nothrow) dmf_problem();
+    if (p == nullptr) return DMF_ERR_BAD_ARG;
+    p->ctx = ctx;
+    p->N = n_idx;
+    p->S = src->S;
+    p->n_c = src->n_c;
+    long long* d_idx = nullptr;
+    int st = DMF_OK;
+    hipError_t e = hipMalloc((void**)&d_idx, (size_t)n_idx * sizeof(long long));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, (size_t)n_idx * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->V, (size_t)n_idx * p->S * sizeof(double));
+    if (e == hipSuccess) p->own_V = true, e = hipMalloc((void**)&p->D, (size_t)n_idx * p->S * sizeof(double));
+    if (e == hipSuccess) p->own_D = true;
+    if (e == hipSuccess && p->n_c > 0) {
+        e = hipMalloc((void**)&p->Rt, (size_t)n_idx * p->n_c * sizeof(double));
+        if (e == hipSuccess) p->own_Rt = true;
+    }
+    if (e == hipSuccess) e = dmf::launch_gather_rows(src->V, p->V, d_idx, n_idx, p->S, ctx->stream);
+    if (e == hipSuccess) e = dmf::launch_gather_rows(src->D, p->D, d_idx, n_idx, p->S, ctx->stream);
+    if (e == hipSuccess && p->n_c > 0) e = dmf::launch_gather_rows(src->Rt, p->Rt, d_idx, n_idx, p->n_c, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d_idx);
+    if (e != hipSuccess) st = hip_fail(e, "row gather", __LINE__);
+    if (st == DMF_OK) st = problem_finalize(p);
+    if (st != DMF_OK) {
+        dmf_problem_destroy(p);
+        return st;
+    }
+    *out = p;
+    return DMF_OK;
+}
+
+int dmf_problem_destroy(dmf_problem* p) {
+    if (p == nullptr) return DMF_OK;
+    hipSetDevice(p->ctx->device);
+    if (p->own_V) hipFree(p->V);
+    if (p->own_D) hipFree(p->D);
+    if (p->own_Rt) hipFree(p->Rt);
+    hipFree(p->consts);
+    hipFree(p->gb_known);
+    delete p;
+    return DMF_OK;
+}
+
+int dmf_problem_shape(const dmf_problem* p, int64_t* N, int64_t* S, int64_t* n_c) {
+    if (p == nullptr) return DMF_ERR_BAD_ARG;
+    if (N) *N = p->N;
+    if (S) *S = p->S;
+    if (n_c) *n_c = p->n_c;
+    return DMF_OK;
+}
+
+// ------------------------------------------------------------------------------- solver
+int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, const double* alpha0,
+                      int64_t n_u, int mode, int flags, dmf_solver** out) {
+    DMF_TRY(check_ctx(ctx));
+    if (out == nullptr) return DMF_ERR_BAD_ARG;
+    *out = nullptr;
+    if (p == nullptr || u0 == nullptr || alpha0 == nullptr || n_u < 1) return DMF_ERR_BAD_ARG;
+    if (mode != DMF_MODE_PARTIAL && mode != DMF_MODE_UNSUPERVISED) return DMF_ERR_BAD_ARG;
+    const int64_t N = p->N, S = p->S, n_c = p->n_c, K = n_c + n_u;
+    if (K > dmf::kMaxK) return DMF_ERR_UNSUPPORTED;
+    dmf_solver* s = new (std::nothrow) dmf_solver();
+    if (s == nullptr) return DMF_ERR_BAD_ARG;
+    s->ctx = ctx;
+    s->p = p;
+    s->n_u = n_u;
+    s->mode = mode;
+    s->use_gram_u = !ctx->force_generic && dmf::u_phase_gram_supported((int)S, (int)n_c, (int)n_u);
+    if (!s->use_gram_u && !dmf::u_step_direct_supported((int)S, (int)n_c, (int)n_u)) {
+        delete s;
+        return DMF_ERR_UNSUPPORTED;
+    }
+    // job table of the per-iteration part of the packed Gram: every (k, l) that involves u
+    std::vector<short> hk, hl;
+    std::vector<int> hd;
+    for (int l = (int)n_c; l <= (int)K; ++l)
+        for (int k = 0; k <= l; ++k) {
+            if (l == (int)K && k < (int)n_c) continue;  // b of the known types is constant
+            if (l == (int)K && k == (int)K) continue;   // v^T D v is constant
+            hk.push_back((short)k);
+            hl.push_back((short)l);
+            hd.push_back(dmf::tri(k, l));
+        }
+    s->n_jobs = (int)hk.size();
+    s->slab_doubles = dmf::gram_slab_doubles(N, (int)S, s->n_jobs);
+    const size_t un = (size_t)N * n_u * sizeof(double), an = (size_t)K * S * sizeof(double);
+    const size_t gbn = (size_t)(K + 1) * (K + 2) / 2 * S * sizeof(double);
+    const int nb_alpha = (int)((S + 63) / 64);
+    hipError_t e = hipMalloc((void**)&s->u, un);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->u_prev, un);
+    if (e == hipSuccess && !s->use_gram_u) e = hipMalloc((void**)&s->u_next, un);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->alpha, an);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->alpha_prev, an);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->gb, gbn);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->slab, (size_t)s->slab_doubles * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->partials, (size_t)2 * nb_alpha * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->state, sizeof(SolverState));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_state, sizeof(SolverState));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->job_k, s->n_jobs * sizeof(short));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->job_l, s->n_jobs * sizeof(short));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->job_dst, s->n_jobs * sizeof(int));
+    const hipMemcpyKind in_kind = (flags & DMF_PTR_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (e == hipSuccess) e = hipMemsetAsync(s->state, 0, sizeof(SolverState), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->gb, 0, gbn, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->u, u0, un, in_kind, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->u_prev, s->u, un, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->alpha, alpha0, an, in_kind, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->alpha_prev, s->alpha, an, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->job_k, hk.data(), s->n_jobs * sizeof(short), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->job_l, hl.data(), s->n_jobs * sizeof(short), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->job_dst, hd.data(), s->n_jobs * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = dmf::launch_scatter_known_block(p->gb_known, s->gb, (int)n_c, (int)K, (int)S, ctx->stream);
+    if (e == hipSuccess) e = dmf::launch_sumsq_f64(s->u, N * n_u, ctx->scratch, &s->state->u_norm2, nullptr, ctx->stream);
+    if (e == hipSuccess) {
+        FamilyScope scope(ctx, DMF_KERNEL_COST);
+        e = dmf::launch_cost(p->V, p->D, p->Rt, s->u, s->alpha, N, (int)S, (int)n_c, (int)n_u,
+                             ctx->scratch + 1024, &s->state->cf, ctx->stream);
+    }
+    if (e == hipSuccess) e = dmf::launch_init_state(s->state, p->consts, s->alpha, (int)S, (int)n_c, (int)n_u, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host job vectors go out of scope
+    if (e != hipSuccess) {
+        dmf_solver_destroy(s);
+        return hip_fail(e, "solver set-up", __LINE__);
+    }
+    *out = s;
+    return DMF_OK;
+}
+
+__global__ void k_set_tol(SolverState* state, double tol) { state->tol = tol; }
+
+int dmf_solver_step(dmf_solver* s, int64_t n_outer, int64_t n_iter2, double tol,
+                    int64_t* iters_done_total, int* converged) {
+    if (s == nullptr || n_outer < 0 || n_iter2 < 0 || n_iter2 > (1 << 20)) return DMF_ERR_BAD_ARG;
+    dmf_context* ctx = s->ctx;
+    DMF_TRY(check_ctx(ctx));
+    hipLaunchKernelGGL(k_set_tol, dim3(1), dim3(1), 0, ctx->stream, s->state, tol);
+    HIP_TRY(hipGetLastError());
+    DMF_TRY(fetch_state(s));
+    // The device freezes the iterate once the stop test fires (every kernel checks state->done),
+    // so the host may run ahead by `check_every` enqueued iterations without overshooting.
+    const int64_t check_every = s->use_gram_u ? 8 : 1;
+    int64_t enqueued = 0;
+    while (enqueued < n_outer && !s->h_state->done) {
+        int64_t batch = n_outer - enqueued < check_every ? n_outer - enqueued : check_every;
+        for (int64_t b = 0; b < batch; ++b) DMF_TRY(enqueue_outer_iteration(s, (int)n_iter2));
+        enqueued += batch;
+        DMF_TRY(fetch_state(s));
+    }
+    if (iters_done_total) *iters_done_total = s->h_state->iters;
+    if (converged) *converged = s->h_state->done;
+    return DMF_OK;
+}
+
+int dmf_solver_get(dmf_solver* s, int flags, double* out_u, double* out_alpha, double* out_cost,
+                   int64_t* out_iters) {
+    if (s == nullptr) return DMF_ERR_BAD_ARG;
+    dmf_context* ctx = s->ctx;
+    DMF_TRY(check_ctx(ctx));
+    const dmf_problem* p = s->p;
+    DMF_TRY(export_array(ctx, s->u, (size_t)p->N * s->n_u * sizeof(double), flags, out_u));
+    DMF_TRY(export_array(ctx, s->alpha, (size_t)(p->n_c + s->n_u) * p->S * sizeof(double), flags, out_alpha));
+    DMF_TRY(fetch_state(s));
+    if (out_cost) *out_cost = s->h_state->cf;
+    if (out_iters) *out_iters = s->h_state->iters;
+    return DMF_OK;
+}
+
+int dmf_solver_destroy(dmf_solver* s) {
+    if (s == nullptr) return DMF_OK;
+    hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->stream);
+    hipFree(s->u);
+    hipFree(s->u_prev);
+    hipFree(s->u_next);
+    hipFree(s->alpha);
+    hipFree(s->alpha_prev);
+    hipFree(s->gb);
+    hipFree(s->slab);
+    hipFree(s->partials);
+    hipFree(s->state);
+    if (s->h_state) hipHostFree(s->h_state);
+    hipFree(s->job_k);
+    hipFree(s->job_l);
+    hipFree(s->job_dst);
+    delete s;
+    return DMF_OK;
+}
+
+int dmf_solve(dmf_context* ctx, const dmf_problem* p, const double* u0, const double* alpha0, int64_t n_u,
+              int mode, int64_t n_iter1, int64_t n_iter2, double tol, int flags, double* out_u,
+              double* out_alpha, double* out_cost, int64_t* out_iters) {
+    dmf_solver* s = nullptr;
+    DMF_TRY(dmf_solver_create(ctx, p, u0, alpha0, n_u, mode, flags, &s));
+    int st = dmf_solver_step(s, n_iter1, n_iter2, tol, nullptr, nullptr);
+    if (st == DMF_OK) st = dmf_solver_get(s, flags, out_u, out_alpha, out_cost, out_iters);
+    dmf_solver_destroy(s);
+    return st;
+}
+
+// ------------------------------------------------------------------------------- single functions
+int dmf_cost(dmf_context* ctx, const dmf_problem* p, const double* u, int64_t n_u, const double* alpha,
+             int flags, double* out_cost) {
+    DMF_TRY(check_ctx(ctx));
+    if (p == nullptr || alpha == nullptr || out_cost == nullptr || n_u < 0) return DMF_ERR_BAD_ARG;
+    if (n_u > 0 && u == nullptr) return DMF_ERR_BAD_ARG;
+    const int64_t K = p->n_c + n_u;
+    if (K < 1) return DMF_ERR_BAD_ARG;
+    double *du = nullptr, *da = nullptr, *dout = nullptr;
+    bool own_u = false, own_a = false;
+    int st = import_array(ctx, u, (size_t)p->N * n_u * sizeof(double), flags, (void**)&du, &own_u);
+    if (st == DMF_OK) st = import_array(ctx, alpha, (size_t)K * p->S * sizeof(double), flags, (void**)&da, &own_a);
+    if (st == DMF_OK) {
+        hipError_t e = hipMalloc((void**)&dout, sizeof(double));
+        if (e == hipSuccess) {
+            FamilyScope scope(ctx, DMF_KERNEL_COST);
+            e = dmf::launch_cost(p->V, p->D, p->Rt, du, da, p->N, (int)p->S, (int)p->n_c, (int)n_u,
+                                 ctx->scratch, dout, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out_cost, dout, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) st = hip_fail(e, "cost", __LINE__);
+    }
+    if (own_u) hipFree(du);
+    if (own_a) hipFree(da);
+    hipFree(dout);
+    return st;
+}
+
+int dmf_project_simplex(dmf_context* ctx, const double* X, int64_t K, int64_t S, double z, int flags,
+                        double* out) {
+    DMF_TRY(check_ctx(ctx));
+    if (X == nullptr || out == nullptr || K < 1 || S < 1) return DMF_ERR_BAD_ARG;
+    if (K > dmf::kMaxK) return DMF_ERR_UNSUPPORTED;
+    const size_t bytes = (size_t)K * S * sizeof(double);
+    double *dx = nullptr, *dout = nullptr;
+    bool own_x = false;
+    int st = import_array(ctx, X, bytes, flags, (void**)&dx, &own_x);
+    if (st == DMF_OK) {
+        hipError_t e = hipSuccess;
+        if (flags & DMF_PTR_DEVICE) dout = out;
+        else e = hipMalloc((void**)&dout, bytes);
+        if (e == hipSuccess) e = dmf::launch_project_simplex(dx, dout, (int)K, (int)S, z, ctx->stream);
+        if (e == hipSuccess && !(flags & DMF_PTR_DEVICE))
+            e = hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) st = hip_fail(e, "project_simplex", __LINE__);
+        if (!(flags & DMF_PTR_DEVICE)) hipFree(dout);
+    }
+    if (own_x) hipFree(dx);
+    return st;
+}
+
+int dmf_update_u(dmf_context* ctx, const dmf_problem* p, const double* u, const double* u_prev,
+                 const double* alpha, int64_t n_u, int64_t n_iter2, int mode, int flags,
+                 double* scalars_io, double* out_u, double* out_u_prev) {
+    if (u_prev == nullptr || scalars_io == nullptr || out_u == nullptr || out_u_prev == nullptr || n_iter2 < 0)
+        return DMF_ERR_BAD_ARG;
+    dmf_solver* s = nullptr;
+    DMF_TRY(dmf_solver_create(ctx, p, u, alpha, n_u, mode, flags, &s));
+    const size_t un = (size_t)p->N * n_u * sizeof(double);
+    const hipMemcpyKind in_kind = (flags & DMF_PTR_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    int st = DMF_OK;
+    hipError_t e = hipMemcpyAsync(s->u_prev, u_prev, un, in_kind, ctx->stream);
+    if (e != hipSuccess) st = hip_fail(e, "copy u_prev", __LINE__);
+    if (st == DMF_OK) st = fetch_state(s);
+    if (st == DMF_OK) {
+        s->h_state->a1 = scalars_io[0];
+        s->h_state->l_w_prev = scalars_io[1];
+        s->h_state->l_w = scalars_io[2];
+        st = push_state(s);
+    }
+    if (st == DMF_OK) st = enqueue_u_phase(s, (int)n_iter2);
+    if (st == DMF_OK) st = export_array(ctx, s->u, un, flags, out_u);
+    if (st == DMF_OK) st = export_array(ctx, s->u_prev, un, flags, out_u_prev);
+    if (st == DMF_OK) {
+        scalars_io[0] = advance_momentum(scalars_io[0], n_iter2);
+        if (n_iter2 > 0) scalars_io[1] = scalars_io[2];
+    }
+    dmf_solver_destroy(s);
+    return st;
+}
+
+int dmf_update_alpha(dmf_context* ctx, const dmf_problem* p, const double* u, int64_t n_u,
+                     const double* alpha, const double* alpha_prev, int64_t n_iter2, int flags,
+                     double* scalars_io, double* out_alpha, double* out_alpha_prev) {
+    if (alpha_prev == nullptr || scalars_io == nullptr || out_alpha == nullptr || out_alpha_prev == nullptr ||
+        n_iter2 < 0)
+        return DMF_ERR_BAD_ARG;
+    dmf_solver* s = nullptr;
+    DMF_TRY(dmf_solver_create(ctx, p, u, alpha, n_u, DMF_MODE_PARTIAL, flags, &s));
+    const size_t an = (size_t)(p->n_c + n_u) * p->S * sizeof(double);
+    const hipMemcpyKind in_kind = (flags & DMF_PTR_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    int st = DMF_OK;
+    hipError_t e = hipMemcpyAsync(s->alpha_prev, alpha_prev, an, in_kind, ctx->stream);
+    if (e != hipSuccess) st = hip_fail(e, "copy alpha_prev", __LINE__);
+    if (st == DMF_OK) st = fetch_state(s);
+    if (st == DMF_OK) {
+        s->h_state->a2 = scalars_io[0];
+        s->h_state->l_h_prev = scalars_io[1];
+        s->h_state->l_h = scalars_io[2];
+        st = push_state(s);
+    }
+    if (st == DMF_OK) st = enqueue_gram(s);
+    if (st == DMF_OK) st = enqueue_alpha_phase(s, (int)n_iter2);
+    if (st == DMF_OK) st = export_array(ctx, s->alpha, an, flags, out_alpha);
+    if (st == DMF_OK) st = export_array(ctx, s->alpha_prev, an, flags, out_alpha_prev);
+    if (st == DMF_OK) {
+        scalars_io[0] = advance_momentum(scalars_io[0], n_iter2);
+        if (n_iter2 > 0) scalars_io[1] = scalars_io[2];
+    }
+    dmf_solver_destroy(s);
+    return st;
+}
+
+}  // extern "C"

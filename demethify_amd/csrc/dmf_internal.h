@@ -1,0 +1,92 @@
+// Internal declarations shared by the kernel translation units and the C-ABI layer.
+// gfx950 only; no portability macros on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dmf {
+
+// Device-resident scalar state of one solve (demethify/deconvolution.py:192-204 and the
+// scalars carried across outer iterations, :206-221).
+struct SolverState {
+    double a1;         // momentum scalar of the u phase (:192, :83-84)
+    double a2;         // momentum scalar of the alpha phase (:193, :95-96)
+    double l_w;        // ||alpha[-n_u:]||_F^2 * d (:198, :216)
+    double l_w_prev;   // l_w_ (:199, :89)
+    double l_h;        // ||R||_F^2 * d (:201, :212)
+    double l_h_prev;   // l_h_ (:202, :101)
+    double dsq;        // d = max(D)^2 (:197)
+    double rt_norm2;   // ||R_trunc||_F^2 (constant part of ||R||_F^2)
+    double u_norm2;    // ||u||_F^2 of the current u
+    double cf;         // current cost (:204, :218)
+    double cf_prev;    // cf_0 (:207)
+    double tol;        // stop threshold of the running step() call (:220)
+    long long iters;   // outer iterations completed
+    int done;          // 1 once |cf - cf_0| < tol was met; later launches are no-ops
+    int pad;
+};
+
+// Packed upper triangle, column-major over (k <= l): independent of the matrix size.
+__host__ __device__ inline int tri(int k, int l) { return l * (l + 1) / 2 + k; }
+
+constexpr int kMaxK = 64;          // largest K = n_c + n_u the alpha kernels are built for
+constexpr int kGramChunk = 16;     // accumulators per generic Gram job
+constexpr int kRowsPerBlockU = 64; // rows handled by one block of the u-phase kernels
+
+struct GramJobTable {              // device arrays, one entry per accumulator
+    const short* k_idx;            // extended index (0..K; K means "the sample column v")
+    const short* l_idx;
+    const int* dst_row;            // destination row in the solver's packed Gram buffer
+    int count;
+};
+
+// ---- launch wrappers (dmf_kernels_*.hip) ---------------------------------------------------
+// All wrappers enqueue on `st` and return the hipGetLastError() of their launches.
+
+hipError_t launch_convert_counts(const long long* src, double* dst, int64_t n, hipStream_t st);
+// max over a f64 array -> *out (device); scratch needs >= 1024 doubles
+hipError_t launch_max_f64(const double* x, int64_t n, double* scratch, double* out, hipStream_t st);
+// sum of squares -> *out (device)
+hipError_t launch_sumsq_f64(const double* x, int64_t n, double* scratch, double* out,
+                            const int* done_flag, hipStream_t st);
+hipError_t launch_gather_rows(const double* src, double* dst, const long long* idx, int64_t n_idx,
+                              int64_t width, hipStream_t st);
+
+// direct weighted cost: *out = sum d (v - [Rt|u] alpha)^2
+hipError_t launch_cost(const double* V, const double* D, const double* Rt, const double* u,
+                       const double* alpha, int64_t N, int S, int n_c, int n_u,
+                       double* scratch, double* out, hipStream_t st);
+
+// generic weighted Gram accumulation over the extended row vector x = (Rt, u, v)
+hipError_t launch_gram(const double* V, const double* D, const double* Rt, const double* u,
+                       int64_t N, int S, int n_c, int n_u, GramJobTable jobs,
+                       double* slab, int64_t slab_doubles, double* gb, const int* done_flag,
+                       hipStream_t st);
+int64_t gram_slab_doubles(int64_t N, int S, int n_jobs);
+
+// u phase, Gram form (n_u <= 8): all n_iter2 inner iterations in one launch
+hipError_t launch_u_phase_gram(const double* V, const double* D, const double* Rt,
+                               const double* alpha, double* u, double* u_prev,
+                               const SolverState* state, int64_t N, int S, int n_c, int n_u,
+                               int n_iter2, int mode, hipStream_t st);
+bool u_phase_gram_supported(int S, int n_c, int n_u);
+// u phase, schedule-faithful fallback: ONE inner iteration (index t) per launch
+hipError_t launch_u_step_direct(const double* V, const double* D, const double* Rt,
+                                const double* alpha, const double* u_cur, const double* u_prev,
+                                double* u_next, const SolverState* state, int64_t N, int S,
+                                int n_c, int n_u, int t, int mode, hipStream_t st);
+bool u_step_direct_supported(int S, int n_c, int n_u);
+
+// alpha phase on the packed Gram buffer gb[(K+1)(K+2)/2][S]
+hipError_t launch_alpha_phase(const double* gb, double* alpha, double* alpha_prev,
+                              SolverState* state, int S, int n_c, int n_u, int n_iter2,
+                              double* partials, hipStream_t st);
+hipError_t launch_set_lh(SolverState* state, hipStream_t st);
+hipError_t launch_project_simplex(const double* X, double* out, int K, int S, double z,
+                                  hipStream_t st);
+hipError_t launch_scatter_known_block(const double* gb_known, double* gb, int n_c, int K, int S,
+                                      hipStream_t st);
+hipError_t launch_init_state(SolverState* state, const double* consts, const double* alpha,
+                             int S, int n_c, int n_u, hipStream_t st);
+
+}  // namespace dmf

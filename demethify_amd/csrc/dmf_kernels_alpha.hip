@@ -1,0 +1,403 @@
+// alpha phase on the packed per-sample Gram buffer, simplex projection, cost and the scalar
+// bookkeeping of one outer iteration (demethify/deconvolution.py:93-102, :21-37, :212-221).
+//
+// gb[(K+1)(K+2)/2][S] is the packed upper triangle (tri(k,l), k <= l <= K) of the extended Gram
+// matrix of x = (R, v) weighted by d: rows tri(k,l<K) are G_s = R^T diag(d_s) R, rows tri(k,K)
+// are b_s = R^T (d_s * v_s), row tri(K,K) is v_s^T D_s v_s.  With them
+//     R^T (d_s * (v_s - R a)) = b_s - G_s a,      cost_s = vDv_s - 2 a.b_s + a^T G_s a.
+#include "dmf_device.h"
+#include "dmf_internal.h"
+
+namespace dmf {
+
+// Compile-time bitonic network, descending; every index is a constant after unrolling so the
+// array stays in registers.
+template <int KMAX>
+__device__ __forceinline__ void sort_desc(double (&x)[KMAX]) {
+#pragma unroll
+    for (int k = 2; k <= KMAX; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < KMAX; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const double lo = fmin(x[i], x[l]), hi = fmax(x[i], x[l]);
+                    if ((i & k) == 0) { x[i] = hi; x[l] = lo; }
+                    else { x[i] = lo; x[l] = hi; }
+                }
+            }
+        }
+    }
+}
+
+// projection_simplex_sort_2d for one column held in registers (deconvolution.py:25-35).
+template <int KMAX>
+__device__ __forceinline__ void project_column(double (&x)[KMAX], int K, double z) {
+    double srt[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) srt[k] = k < K ? x[k] : -INFINITY;
+    sort_desc<KMAX>(srt);
+    double run = 0.0, theta = 0.0;
+    bool any = false;
+    double last_shift = 0.0;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        if (j < K) {
+            run += srt[j];
+            const double shifted = run - z;
+            if (srt[j] - shifted / (double)(j + 1) > 0.0) {
+                theta = shifted / (double)(j + 1);
+                any = true;
+            }
+            last_shift = shifted;
+        }
+    }
+    if (!any) theta = last_shift / 0.0;  // upstream: rho = -1 -> pi[-1] / 0 (only for non-finite input)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) x[k] = k < K ? fmax(x[k] - theta, 0.0) : 0.0;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(64) void k_alpha_phase(const double* __restrict__ gb,
+                                                    double* __restrict__ alpha,
+                                                    double* __restrict__ alpha_prev,
+                                                    const SolverState* __restrict__ state, int S,
+                                                    int K, int n_u, int n_iter2, int gb_in_lds,
+                                                    double* __restrict__ partials) {
+    extern __shared__ double lds_dyn[];
+    if (state->done) return;
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x * 64 + tid;
+    const bool active = s < S;
+    const int sc = active ? s : S - 1;
+    const int nrows = (K + 1) * (K + 2) / 2;
+    if (gb_in_lds) {
+        for (int r = 0; r < nrows; ++r) lds_dyn[r * 64 + tid] = gb[(int64_t)r * S + sc];
+    }
+    const double* G = gb_in_lds ? (const double*)lds_dyn + tid : gb + sc;
+    const int64_t gstride = gb_in_lds ? 64 : S;
+
+    double a[KMAX], ap[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        a[k] = k < K ? alpha[(int64_t)k * S + sc] : 0.0;
+        ap[k] = k < K ? alpha_prev[(int64_t)k * S + sc] : 0.0;
+    }
+    double a2 = state->a2, lh_prev = state->l_h_prev;
+    const double lh = state->l_h;
+    for (int t = 0; t < n_iter2; ++t) {
+        double beta;
+        momentum_step(a2, lh_prev, lh, beta);
+        double at[KMAX], g[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            at[k] = a[k] + beta * (a[k] - ap[k]);
+            ap[k] = a[k];
+            g[k] = k < K ? G[tri(k, K) * gstride] : 0.0;
+        }
+#pragma unroll
+        for (int l = 0; l < KMAX; ++l) {
+            if (l < K) {
+#pragma unroll
+                for (int k = 0; k <= l; ++k) {
+                    const double gkl = G[tri(k, l) * gstride];
+                    g[k] = fma(-gkl, at[l], g[k]);
+                    if (k != l) g[l] = fma(-gkl, at[k], g[l]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) a[k] = at[k] + g[k] / lh;
+        project_column<KMAX>(a, K, 1.0);
+        lh_prev = lh;
+    }
+    double cost = 0.0, n2 = 0.0;
+    if (active) {
+        cost = G[tri(K, K) * gstride];
+        double lin = 0.0, quad = 0.0;
+#pragma unroll
+        for (int l = 0; l < KMAX; ++l) {
+            if (l < K) {
+                alpha[(int64_t)l * S + s] = a[l];
+                alpha_prev[(int64_t)l * S + s] = ap[l];
+                lin = fma(a[l], G[tri(l, K) * gstride], lin);
+                double off = 0.0;
+#pragma unroll
+                for (int k = 0; k < l; ++k) off = fma(G[tri(k, l) * gstride], a[k], off);
+                quad = fma(a[l], fma(2.0, off, G[tri(l, l) * gstride] * a[l]), quad);
+                if (l >= K - n_u) n2 = fma(a[l], a[l], n2);
+            }
+        }
+        cost = cost - 2.0 * lin + quad;
+    }
+    cost = wave_sum(cost);
+    n2 = wave_sum(n2);
+    if (tid == 0) {
+        partials[2 * blockIdx.x] = cost;
+        partials[2 * blockIdx.x + 1] = n2;
+    }
+}
+
+// ---- runtime-K variants (16 < K <= 64): per-thread arrays live in scratch, loops are not unrolled.
+// Rare path (model-selection sweeps with many unknown types); kept small to keep the build short.
+__device__ __noinline__ void project_column_dyn(double* x, int K, double z) {
+    double srt[kMaxK];
+    for (int k = 0; k < K; ++k) {  // insertion sort, descending
+        const double v = x[k];
+        int j = k;
+        while (j > 0 && srt[j - 1] < v) {
+            srt[j] = srt[j - 1];
+            --j;
+        }
+        srt[j] = v;
+    }
+    double run = 0.0, theta = 0.0, last_shift = 0.0;
+    bool any = false;
+    for (int j = 0; j < K; ++j) {
+        run += srt[j];
+        const double shifted = run - z;
+        if (srt[j] - shifted / (double)(j + 1) > 0.0) {
+            theta = shifted / (double)(j + 1);
+            any = true;
+        }
+        last_shift = shifted;
+    }
+    if (!any) theta = last_shift / 0.0;
+    for (int k = 0; k < K; ++k) x[k] = fmax(x[k] - theta, 0.0);
+}
+
+__global__ __launch_bounds__(64) void k_alpha_phase_dyn(const double* __restrict__ gb,
+                                                        double* __restrict__ alpha,
+                                                        double* __restrict__ alpha_prev,
+                                                        const SolverState* __restrict__ state, int S,
+                                                        int K, int n_u, int n_iter2,
+                                                        double* __restrict__ partials) {
+    if (state->done) return;
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x * 64 + tid;
+    const bool active = s < S;
+    const int sc = active ? s : S - 1;
+    const double* G = gb + sc;
+    const int64_t gstride = S;
+    double a[kMaxK], ap[kMaxK], at[kMaxK], g[kMaxK];
+    for (int k = 0; k < K; ++k) {
+        a[k] = alpha[(int64_t)k * S + sc];
+        ap[k] = alpha_prev[(int64_t)k * S + sc];
+    }
+    double a2 = state->a2, lh_prev = state->l_h_prev;
+    const double lh = state->l_h;
+    for (int t = 0; t < n_iter2; ++t) {
+        double beta;
+        momentum_step(a2, lh_prev, lh, beta);
+        for (int k = 0; k < K; ++k) {
+            at[k] = a[k] + beta * (a[k] - ap[k]);
+            ap[k] = a[k];
+            g[k] = G[tri(k, K) * gstride];
+        }
+        for (int l = 0; l < K; ++l)
+            for (int k = 0; k <= l; ++k) {
+                const double gkl = G[tri(k, l) * gstride];
+                g[k] = fma(-gkl, at[l], g[k]);
+                if (k != l) g[l] = fma(-gkl, at[k], g[l]);
+            }
+        for (int k = 0; k < K; ++k) a[k] = at[k] + g[k] / lh;
+        project_column_dyn(a, K, 1.0);
+        lh_prev = lh;
+    }
+    double cost = 0.0, n2 = 0.0;
+    if (active) {
+        cost = G[tri(K, K) * gstride];
+        double lin = 0.0, quad = 0.0;
+        for (int l = 0; l < K; ++l) {
+            alpha[(int64_t)l * S + s] = a[l];
+            alpha_prev[(int64_t)l * S + s] = ap[l];
+            lin = fma(a[l], G[tri(l, K) * gstride], lin);
+            double off = 0.0;
+            for (int k = 0; k < l; ++k) off = fma(G[tri(k, l) * gstride], a[k], off);
+            quad = fma(a[l], fma(2.0, off, G[tri(l, l) * gstride] * a[l]), quad);
+            if (l >= K - n_u) n2 = fma(a[l], a[l], n2);
+        }
+        cost = cost - 2.0 * lin + quad;
+    }
+    cost = wave_sum(cost);
+    n2 = wave_sum(n2);
+    if (tid == 0) {
+        partials[2 * blockIdx.x] = cost;
+        partials[2 * blockIdx.x + 1] = n2;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_project_dyn(const double* __restrict__ X, double* __restrict__ out,
+                                                    int K, int S, double z) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= S) return;
+    double x[kMaxK];
+    for (int k = 0; k < K; ++k) x[k] = X[(int64_t)k * S + s];
+    project_column_dyn(x, K, z);
+    for (int k = 0; k < K; ++k) out[(int64_t)k * S + s] = x[k];
+}
+
+// Closes one outer iteration: sums the per-block partials and advances the scalar state
+// (deconvolution.py:207, :216-221; a1/a2 advance exactly as the inner loops advanced them).
+__global__ __launch_bounds__(64) void k_finish_iteration(const double* __restrict__ partials, int nb,
+                                                         SolverState* __restrict__ state,
+                                                         int n_iter2) {
+    if (state->done) return;
+    double cost = 0.0, n2 = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 64) {
+        cost += partials[2 * b];
+        n2 += partials[2 * b + 1];
+    }
+    cost = wave_sum(cost);
+    n2 = wave_sum(n2);
+    if (threadIdx.x == 0) {
+        double a1 = state->a1, a2 = state->a2;
+        for (int t = 0; t < n_iter2; ++t) {
+            a1 = (1.0 + sqrt(1.0 + 4.0 * a1 * a1)) / 2.0;
+            a2 = (1.0 + sqrt(1.0 + 4.0 * a2 * a2)) / 2.0;
+        }
+        state->a1 = a1;
+        state->a2 = a2;
+        if (n_iter2 > 0) {
+            state->l_w_prev = state->l_w;
+            state->l_h_prev = state->l_h;
+        }
+        state->l_w = n2 * state->dsq;
+        const double cf_prev = state->cf;
+        state->cf_prev = cf_prev;
+        state->cf = cost;
+        state->iters += 1;
+        if (fabs(cost - cf_prev) < state->tol) state->done = 1;
+    }
+}
+
+__global__ void k_set_lh(SolverState* state) {
+    if (state->done) return;
+    state->l_h = (state->rt_norm2 + state->u_norm2) * state->dsq;
+}
+
+hipError_t launch_set_lh(SolverState* state, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_lh, dim3(1), dim3(1), 0, st, state);
+    return hipGetLastError();
+}
+
+template <int KMAX>
+static hipError_t launch_alpha_t(const double* gb, double* alpha, double* alpha_prev,
+                                 SolverState* state, int S, int K, int n_u, int n_iter2,
+                                 double* partials, hipStream_t st) {
+    const int nb = (S + 63) / 64;
+    const size_t lds = (size_t)(K + 1) * (K + 2) / 2 * 64 * sizeof(double);
+    const int in_lds = lds <= 150 * 1024;
+    if (in_lds && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_alpha_phase<KMAX>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_alpha_phase<KMAX>, dim3(nb), dim3(64), in_lds ? lds : 0, st, gb, alpha,
+                       alpha_prev, state, S, K, n_u, n_iter2, in_lds, partials);
+    hipLaunchKernelGGL(k_finish_iteration, dim3(1), dim3(64), 0, st, partials, nb, state, n_iter2);
+    return hipGetLastError();
+}
+
+hipError_t launch_alpha_phase(const double* gb, double* alpha, double* alpha_prev,
+                              SolverState* state, int S, int n_c, int n_u, int n_iter2,
+                              double* partials, hipStream_t st) {
+    const int K = n_c + n_u;
+    if (K <= 4) return launch_alpha_t<4>(gb, alpha, alpha_prev, state, S, K, n_u, n_iter2, partials, st);
+    if (K <= 8) return launch_alpha_t<8>(gb, alpha, alpha_prev, state, S, K, n_u, n_iter2, partials, st);
+    if (K <= 16) return launch_alpha_t<16>(gb, alpha, alpha_prev, state, S, K, n_u, n_iter2, partials, st);
+    if (K <= kMaxK) {
+        const int nb = (S + 63) / 64;
+        hipLaunchKernelGGL(k_alpha_phase_dyn, dim3(nb), dim3(64), 0, st, gb, alpha, alpha_prev, state, S, K,
+                           n_u, n_iter2, partials);
+        hipLaunchKernelGGL(k_finish_iteration, dim3(1), dim3(64), 0, st, partials, nb, state, n_iter2);
+        return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- standalone projection (KAT entry point) ----------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(64) void k_project(const double* __restrict__ X, double* __restrict__ out,
+                                                int K, int S, double z) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= S) return;
+    double x[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) x[k] = k < K ? X[(int64_t)k * S + s] : 0.0;
+    project_column<KMAX>(x, K, z);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) out[(int64_t)k * S + s] = x[k];
+}
+
+hipError_t launch_project_simplex(const double* X, double* out, int K, int S, double z,
+                                  hipStream_t st) {
+    const dim3 grid((S + 63) / 64), block(64);
+    if (K <= 4) hipLaunchKernelGGL(k_project<4>, grid, block, 0, st, X, out, K, S, z);
+    else if (K <= 8) hipLaunchKernelGGL(k_project<8>, grid, block, 0, st, X, out, K, S, z);
+    else if (K <= 16) hipLaunchKernelGGL(k_project<16>, grid, block, 0, st, X, out, K, S, z);
+    else if (K <= kMaxK) hipLaunchKernelGGL(k_project_dyn, grid, block, 0, st, X, out, K, S, z);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---- solver set-up helpers -------------------------------------------------------------------
+// Copy the problem's known block (packed triangle over the n_c+1 extended indices (Rt, v)) into
+// the solver's packed buffer over (Rt, u, v): index n_c ("v") moves to K.
+__global__ __launch_bounds__(256) void k_scatter_known(const double* __restrict__ gb_known,
+                                                       double* __restrict__ gb, int n_c, int K, int S) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    for (int l = 0; l <= n_c; ++l) {
+        const int ld = l == n_c ? K : l;
+        for (int k = 0; k <= l; ++k) {
+            const int kd = k == n_c ? K : k;
+            gb[(int64_t)tri(kd, ld) * S + s] = gb_known[(int64_t)tri(k, l) * S + s];
+        }
+    }
+}
+
+hipError_t launch_scatter_known_block(const double* gb_known, double* gb, int n_c, int K, int S,
+                                      hipStream_t st) {
+    hipLaunchKernelGGL(k_scatter_known, dim3((S + 255) / 256), dim3(256), 0, st, gb_known, gb, n_c, K, S);
+    return hipGetLastError();
+}
+
+// State init (deconvolution.py:192-204).  Expects state->u_norm2 and state->cf already written
+// by the sum-of-squares and cost launches that precede it on the stream.
+__global__ __launch_bounds__(256) void k_init_state(SolverState* __restrict__ state,
+                                                    const double* __restrict__ consts,
+                                                    const double* __restrict__ alpha, int S, int n_c,
+                                                    int n_u) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const double* A2 = alpha + (int64_t)n_c * S;
+    for (int i = threadIdx.x; i < n_u * S; i += 256) acc = fma(A2[i], A2[i], acc);
+    const double n2 = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) {
+        const double dsq = consts[0], rt2 = consts[1];
+        state->a1 = 1.0;
+        state->a2 = 1.0;
+        state->dsq = dsq;
+        state->rt_norm2 = rt2;
+        state->l_w = n2 * dsq;
+        state->l_w_prev = state->l_w;
+        state->l_h = (rt2 + state->u_norm2) * dsq;
+        state->l_h_prev = state->l_h;
+        state->cf_prev = state->cf;
+        state->tol = 0.0;
+        state->iters = 0;
+        state->done = 0;
+        state->pad = 0;
+    }
+}
+
+hipError_t launch_init_state(SolverState* state, const double* consts, const double* alpha, int S,
+                             int n_c, int n_u, hipStream_t st) {
+    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(256), 0, st, state, consts, alpha, S, n_c, n_u);
+    return hipGetLastError();
+}
+
+}  // namespace dmf

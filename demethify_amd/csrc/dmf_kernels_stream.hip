@@ -1,0 +1,271 @@
+// Streaming kernels: count conversion, reductions, row gather, the direct weighted cost
+// (demethify/deconvolution.py:15-17) and the generic per-sample weighted Gram accumulation
+// that feeds the alpha phase (G_s = R^T diag(d_s) R, b_s = R^T (d_s * v_s)).
+#include "dmf_device.h"
+#include "dmf_internal.h"
+
+namespace dmf {
+
+// ------------------------------------------------------------------ small utilities
+__global__ __launch_bounds__(256) void k_convert_counts(const long long* __restrict__ src,
+                                                        double* __restrict__ dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) dst[i] = (double)src[i];
+}
+
+hipError_t launch_convert_counts(const long long* src, double* dst, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_convert_counts, dim3(blocks), dim3(256), 0, st, src, dst, n);
+    return hipGetLastError();
+}
+
+template <bool SQUARE_SUM>
+__global__ __launch_bounds__(256) void k_reduce_partial(const double* __restrict__ x, int64_t n,
+                                                        double* __restrict__ partial,
+                                                        const int* __restrict__ done_flag) {
+    __shared__ double red[4];
+    if (done_flag != nullptr && *done_flag) return;
+    double acc = SQUARE_SUM ? 0.0 : -INFINITY;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const double v = x[i];
+        if (SQUARE_SUM) acc = fma(v, v, acc);
+        else acc = fmax(acc, v);
+    }
+    const double tot = SQUARE_SUM ? block_sum<256>(acc, red) : block_max<256>(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+template <bool SQUARE_SUM>
+__global__ __launch_bounds__(256) void k_reduce_final(const double* __restrict__ partial, int n,
+                                                      double* __restrict__ out,
+                                                      const int* __restrict__ done_flag) {
+    __shared__ double red[4];
+    if (done_flag != nullptr && *done_flag) return;
+    double acc = SQUARE_SUM ? 0.0 : -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        if (SQUARE_SUM) acc += partial[i];
+        else acc = fmax(acc, partial[i]);
+    }
+    const double tot = SQUARE_SUM ? block_sum<256>(acc, red) : block_max<256>(acc, red);
+    if (threadIdx.x == 0) *out = tot;
+}
+
+static inline int reduce_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+hipError_t launch_max_f64(const double* x, int64_t n, double* scratch, double* out, hipStream_t st) {
+    const int nb = reduce_blocks(n);
+    hipLaunchKernelGGL(k_reduce_partial<false>, dim3(nb), dim3(256), 0, st, x, n, scratch, (const int*)nullptr);
+    hipLaunchKernelGGL(k_reduce_final<false>, dim3(1), dim3(256), 0, st, scratch, nb, out, (const int*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_sumsq_f64(const double* x, int64_t n, double* scratch, double* out,
+                            const int* done_flag, hipStream_t st) {
+    const int nb = reduce_blocks(n);
+    hipLaunchKernelGGL(k_reduce_partial<true>, dim3(nb), dim3(256), 0, st, x, n, scratch, done_flag);
+    hipLaunchKernelGGL(k_reduce_final<true>, dim3(1), dim3(256), 0, st, scratch, nb, out, done_flag);
+    return hipGetLastError();
+}
+
+// dst[r][:] = src[idx[r]][:]; one wave per destination row chunk (bootstrap.py:28)
+__global__ __launch_bounds__(256) void k_gather_rows(const double* __restrict__ src,
+                                                     double* __restrict__ dst,
+                                                     const long long* __restrict__ idx,
+                                                     int64_t n_idx, int64_t width) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (; r < n_idx; r += stride) {
+        const double* s = src + idx[r] * width;
+        double* d = dst + r * width;
+        for (int64_t c = lane; c < width; c += 64) d[c] = s[c];
+    }
+}
+
+hipError_t launch_gather_rows(const double* src, double* dst, const long long* idx, int64_t n_idx,
+                              int64_t width, hipStream_t st) {
+    if (n_idx <= 0 || width <= 0) return hipSuccess;
+    int64_t b = (n_idx + 3) / 4;
+    if (b > 65536) b = 65536;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)b), dim3(256), 0, st, src, dst, idx, n_idx, width);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ direct weighted cost
+// sum_{i,s} d_is (v_is - sum_k R_ik alpha_ks)^2 with R = [Rt | u]; alpha staged in LDS when it fits.
+__global__ __launch_bounds__(256) void k_cost(const double* __restrict__ V, const double* __restrict__ D,
+                                              const double* __restrict__ Rt, const double* __restrict__ u,
+                                              const double* __restrict__ alpha, int64_t N, int S,
+                                              int n_c, int n_u, int alpha_in_lds,
+                                              double* __restrict__ partial) {
+    extern __shared__ double lds_dyn[];
+    __shared__ double red[4];
+    const int K = n_c + n_u;
+    const double* A = alpha;
+    if (alpha_in_lds) {
+        for (int i = threadIdx.x; i < K * S; i += 256) lds_dyn[i] = alpha[i];
+        __syncthreads();
+        A = lds_dyn;
+    }
+    const int tpr = S < 256 ? S : 256;      // threads per row
+    const int rows_per_tile = 256 / tpr;
+    const int r = threadIdx.x / tpr, c = threadIdx.x - r * tpr;
+    double acc = 0.0;
+    if (r < rows_per_tile) {
+        for (int64_t i = (int64_t)blockIdx.x * rows_per_tile + r; i < N;
+             i += (int64_t)gridDim.x * rows_per_tile) {
+            const double* rt_row = Rt + i * n_c;
+            const double* u_row = u + i * n_u;
+            for (int s = c; s < S; s += tpr) {
+                double pred = 0.0;
+                for (int k = 0; k < n_c; ++k) pred = fma(rt_row[k], A[k * S + s], pred);
+                for (int j = 0; j < n_u; ++j) pred = fma(u_row[j], A[(n_c + j) * S + s], pred);
+                const double e = V[i * S + s] - pred;
+                acc = fma(D[i * S + s] * e, e, acc);
+            }
+        }
+    }
+    const double tot = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+hipError_t launch_cost(const double* V, const double* D, const double* Rt, const double* u,
+                       const double* alpha, int64_t N, int S, int n_c, int n_u,
+                       double* scratch, double* out, hipStream_t st) {
+    const int K = n_c + n_u;
+    const int tpr = S < 256 ? S : 256;
+    const int rows_per_tile = 256 / tpr;
+    int64_t tiles = (N + rows_per_tile - 1) / rows_per_tile;
+    const int nb = (int)(tiles < 1024 ? (tiles < 1 ? 1 : tiles) : 1024);
+    const size_t lds = (size_t)K * S * sizeof(double);
+    const int in_lds = lds <= 48 * 1024;
+    hipLaunchKernelGGL(k_cost, dim3(nb), dim3(256), in_lds ? lds : 0, st, V, D, Rt, u, alpha, N, S,
+                       n_c, n_u, in_lds, scratch);
+    hipLaunchKernelGGL(k_reduce_final<true>, dim3(1), dim3(256), 0, st, scratch, nb, out,
+                       (const int*)nullptr);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ generic weighted Gram
+// Extended row vector x_i(s) = (Rt_i0..Rt_i,nc-1, u_i0..u_i,nu-1, v_is).  Accumulator a with
+// indices (k, l) holds sum_i d_is x_ik x_il for every sample s: (k,l < K) a Gram entry,
+// (k < K, l = K) an entry of b_s = R^T (d_s * v_s), (K, K) the constant v_s^T D_s v_s.
+static void gram_geometry(int64_t N, int S, int n_jobs, int* nsx, int* nz, int* ny,
+                          int64_t* rows_per_chunk) {
+    *nsx = (S + 63) / 64;
+    *nz = (n_jobs + kGramChunk - 1) / kGramChunk;
+    int64_t want = 4096 / ((int64_t)(*nsx) * (*nz));
+    if (want < 1) want = 1;
+    int64_t rpc = (N + want - 1) / want;
+    if (rpc < 256) rpc = 256;
+    *rows_per_chunk = rpc;
+    *ny = (int)((N + rpc - 1) / rpc);
+    if (*ny < 1) *ny = 1;
+}
+
+int64_t gram_slab_doubles(int64_t N, int S, int n_jobs) {
+    int nsx, nz, ny;
+    int64_t rpc;
+    gram_geometry(N, S, n_jobs, &nsx, &nz, &ny, &rpc);
+    return (int64_t)ny * n_jobs * S;
+}
+
+__device__ __forceinline__ double ext_row_value(const double* __restrict__ Rt,
+                                                const double* __restrict__ u, int64_t i, int n_c,
+                                                int n_u, int k, double v) {
+    if (k < n_c) return Rt[i * n_c + k];
+    if (k < n_c + n_u) return u[i * n_u + (k - n_c)];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ V, const double* __restrict__ D,
+                                              const double* __restrict__ Rt, const double* __restrict__ u,
+                                              int64_t N, int S, int n_c, int n_u,
+                                              const short* __restrict__ k_idx,
+                                              const short* __restrict__ l_idx, int n_jobs,
+                                              int64_t rows_per_chunk, double* __restrict__ slab,
+                                              const int* __restrict__ done_flag) {
+    __shared__ double red[3][kGramChunk][64];
+    if (done_flag != nullptr && *done_flag) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 64 + lane;
+    const bool active = s < S;
+    const int a0 = blockIdx.z * kGramChunk;
+    int kk[kGramChunk], ll[kGramChunk];
+#pragma unroll
+    for (int p = 0; p < kGramChunk; ++p) {
+        const int a = a0 + p < n_jobs ? a0 + p : n_jobs - 1;  // clamp: padded slots repeat the last job
+        kk[p] = k_idx[a];
+        ll[p] = l_idx[a];
+    }
+    double acc[kGramChunk];
+#pragma unroll
+    for (int p = 0; p < kGramChunk; ++p) acc[p] = 0.0;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < N ? r0 + rows_per_chunk : N;
+    for (int64_t i = r0 + wave; i < r1; i += 4) {
+        const double d = active ? D[i * S + s] : 0.0;
+        const double v = active ? V[i * S + s] : 0.0;
+#pragma unroll
+        for (int p = 0; p < kGramChunk; ++p) {
+            const double xk = ext_row_value(Rt, u, i, n_c, n_u, kk[p], v);
+            const double xl = ext_row_value(Rt, u, i, n_c, n_u, ll[p], v);
+            acc[p] = fma(d * xk, xl, acc[p]);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int p = 0; p < kGramChunk; ++p) red[wave - 1][p][lane] = acc[p];
+    }
+    __syncthreads();
+    if (wave == 0 && active) {
+#pragma unroll
+        for (int p = 0; p < kGramChunk; ++p) {
+            if (a0 + p < n_jobs) {
+                const double tot = ((acc[p] + red[0][p][lane]) + red[1][p][lane]) + red[2][p][lane];
+                slab[((int64_t)blockIdx.y * n_jobs + (a0 + p)) * S + s] = tot;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ slab, int ny,
+                                                     int n_jobs, int S,
+                                                     const int* __restrict__ dst_row,
+                                                     double* __restrict__ gb,
+                                                     const int* __restrict__ done_flag) {
+    if (done_flag != nullptr && *done_flag) return;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int a = blockIdx.y;
+    if (s >= S) return;
+    double tot = 0.0;
+    for (int y = 0; y < ny; ++y) tot += slab[((int64_t)y * n_jobs + a) * S + s];
+    gb[(int64_t)dst_row[a] * S + s] = tot;
+}
+
+hipError_t launch_gram(const double* V, const double* D, const double* Rt, const double* u,
+                       int64_t N, int S, int n_c, int n_u, GramJobTable jobs, double* slab,
+                       int64_t slab_doubles, double* gb, const int* done_flag, hipStream_t st) {
+    if (jobs.count <= 0) return hipSuccess;
+    int nsx, nz, ny;
+    int64_t rpc;
+    gram_geometry(N, S, jobs.count, &nsx, &nz, &ny, &rpc);
+    if ((int64_t)ny * jobs.count * S > slab_doubles) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_gram, dim3(nsx, ny, nz), dim3(256), 0, st, V, D, Rt, u, N, S, n_c, n_u,
+                       jobs.k_idx, jobs.l_idx, jobs.count, rpc, slab, done_flag);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((S + 255) / 256, jobs.count), dim3(256), 0, st, slab, ny,
+                       jobs.count, S, jobs.dst_row, gb, done_flag);
+    return hipGetLastError();
+}
+
+}  // namespace dmf

@@ -1,0 +1,274 @@
+"""Object wrappers over the C-ABI handles: Context (one per GPU), Problem (V, D, R_trunc resident
+in HBM) and Solver (the outer loop's device-resident state).
+
+Inputs may be host numpy arrays (uploaded by the library) or PyTorch-ROCm tensors already on
+the context's GPU (borrowed through ``data_ptr()``; torch is used for nothing else).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib as L
+
+_contexts: dict[int, "Context"] = {}
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _host_f64(x, name):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if not np.all(np.isfinite(a)):
+        # upstream lets NaN propagate silently; a device solve cannot stop on it
+        raise ValueError(f"{name} holds non-finite values (use --fillna)")
+    return a
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if _is_torch(a):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """dmf_context: a GPU, a HIP stream and the kernel-family clocks."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._lib = L.load()
+        h = C.c_void_p()
+        L.check(self._lib.dmf_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)),
+                "dmf_context_create")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dmf_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover - interpreter teardown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        L.check(self._lib.dmf_context_synchronize(self._h), "dmf_context_synchronize")
+
+    def set_profiling(self, enabled: bool):
+        L.check(self._lib.dmf_context_set_profiling(self._h, int(bool(enabled))), "dmf_context_set_profiling")
+
+    def set_generic(self, enabled: bool):
+        """Force the any-shape kernels (used by tests to cover the fallback path)."""
+        L.check(self._lib.dmf_context_set_generic(self._h, int(bool(enabled))), "dmf_context_set_generic")
+
+    def reset_kernel_time(self):
+        L.check(self._lib.dmf_context_reset_kernel_time(self._h), "dmf_context_reset_kernel_time")
+
+    def kernel_time(self, family: int):
+        """(total milliseconds, launches) accumulated for one kernel family while profiling."""
+        ms, n = C.c_double(), C.c_int64()
+        L.check(self._lib.dmf_context_kernel_time(self._h, int(family), C.byref(ms), C.byref(n)),
+                "dmf_context_kernel_time")
+        return ms.value, n.value
+
+    # ---- single-function entry points -------------------------------------------------
+    def project_simplex(self, X, z=1.0):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        out = np.empty_like(X)
+        K, S = X.shape
+        L.check(self._lib.dmf_project_simplex(self._h, _ptr(X), K, S, float(z), 0, _ptr(out)),
+                "dmf_project_simplex")
+        return out
+
+
+def get_context(device: int | None = None) -> Context:
+    """Process-wide context cache; default device = LOCAL_RANK (one process per GPU) or 0."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = _contexts[device] = Context(device)
+    return ctx
+
+
+class Problem:
+    """dmf_problem: meth_frequency (N x S), counts (N x S), R_trunc (N x n_c or None)."""
+
+    def __init__(self, ctx: Context, V, counts, Rt=None):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        flags = 0
+        if _is_torch(V):
+            import torch
+
+            flags |= L.DMF_PTR_DEVICE
+            for t in (V, counts) + ((Rt,) if Rt is not None else ()):
+                if not (t.is_cuda and t.is_contiguous() and t.device.index == ctx.device):
+                    raise ValueError("device tensors must be contiguous and on the context's GPU")
+            if V.dtype != torch.float64 or (Rt is not None and Rt.dtype != torch.float64):
+                raise ValueError("V and R_trunc must be float64")
+            if counts.dtype == torch.float64:
+                flags |= L.DMF_COUNTS_F64
+            elif counts.dtype != torch.int64:
+                raise ValueError("counts must be int64 or float64")
+            N, S = V.shape
+        else:
+            V = _host_f64(V, "meth_frequency")
+            counts = np.asarray(counts)
+            if counts.dtype.kind in "iub":
+                counts = np.ascontiguousarray(counts, dtype=np.int64)
+            else:
+                counts = _host_f64(counts, "counts")
+                flags |= L.DMF_COUNTS_F64
+            if Rt is not None:
+                Rt = _host_f64(Rt, "R_trunc")
+            N, S = V.shape
+        if tuple(counts.shape) != (N, S):
+            raise ValueError(f"counts shape {tuple(counts.shape)} != meth_frequency shape {(N, S)}")
+        n_c = 0
+        if Rt is not None:
+            if Rt.ndim != 2 or Rt.shape[0] != N:
+                raise ValueError(f"R_trunc shape {tuple(Rt.shape)} does not match {N} CpG rows")
+            n_c = int(Rt.shape[1])
+        self._keep = (V, counts, Rt)  # device tensors are borrowed: keep them alive
+        self.N, self.S, self.n_c = int(N), int(S), n_c
+        h = C.c_void_p()
+        L.check(self._lib.dmf_problem_create(ctx._h, self.N, self.S, self.n_c, _ptr(V), _ptr(counts),
+                                             _ptr(Rt) if n_c else None, flags, C.byref(h)),
+                "dmf_problem_create")
+        self._h = h
+
+    @classmethod
+    def _from_handle(cls, ctx, h, N, S, n_c):
+        self = cls.__new__(cls)
+        self.ctx, self._lib, self._h = ctx, ctx._lib, h
+        self.N, self.S, self.n_c = N, S, n_c
+        self._keep = ()
+        return self
+
+    def gather(self, idx) -> "Problem":
+        """Row-resampled copy (one bootstrap replicate, bootstrap.py:28)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        h = C.c_void_p()
+        L.check(self._lib.dmf_problem_gather(self.ctx._h, self._h, _ptr(idx), idx.size, C.byref(h)),
+                "dmf_problem_gather")
+        return Problem._from_handle(self.ctx, h, int(idx.size), self.S, self.n_c)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dmf_problem_destroy(self._h)
+            self._h = None
+            self._keep = ()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- single-function entry points ---------------------------------------------------
+    def cost(self, u, alpha) -> float:
+        """cost_f_w with R = [R_trunc | u] (deconvolution.py:15-17)."""
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        n_u = 0
+        if u is not None:
+            u = np.ascontiguousarray(u, dtype=np.float64).reshape(self.N, -1)
+            n_u = u.shape[1]
+        if alpha.shape != (self.n_c + n_u, self.S):
+            raise ValueError(f"alpha shape {alpha.shape} != {(self.n_c + n_u, self.S)}")
+        out = C.c_double()
+        L.check(self._lib.dmf_cost(self.ctx._h, self._h, _ptr(u) if n_u else None, n_u, _ptr(alpha), 0,
+                                   C.byref(out)), "dmf_cost")
+        return out.value
+
+    def update_u(self, u, u_prev, alpha, n_iter2, a1, l_w_prev, l_w, mode=L.DMF_MODE_PARTIAL):
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(self.N, -1)
+        u_prev = np.ascontiguousarray(u_prev, dtype=np.float64).reshape(u.shape)
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        n_u = u.shape[1]
+        if alpha.shape != (self.n_c + n_u, self.S):
+            raise ValueError(f"alpha shape {alpha.shape} != {(self.n_c + n_u, self.S)}")
+        sc = (C.c_double * 3)(float(a1), float(l_w_prev), float(l_w))
+        out_u, out_up = np.empty_like(u), np.empty_like(u)
+        L.check(self._lib.dmf_update_u(self.ctx._h, self._h, _ptr(u), _ptr(u_prev), _ptr(alpha), n_u,
+                                       int(n_iter2), int(mode), 0, sc, _ptr(out_u), _ptr(out_up)),
+                "dmf_update_u")
+        return out_u, out_up, sc[0], sc[1]
+
+    def update_alpha(self, u, alpha, alpha_prev, n_iter2, a2, l_h_prev, l_h):
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(self.N, -1)
+        alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+        alpha_prev = np.ascontiguousarray(alpha_prev, dtype=np.float64)
+        n_u = u.shape[1]
+        if alpha.shape != (self.n_c + n_u, self.S) or alpha_prev.shape != alpha.shape:
+            raise ValueError(f"alpha shape {alpha.shape} != {(self.n_c + n_u, self.S)}")
+        sc = (C.c_double * 3)(float(a2), float(l_h_prev), float(l_h))
+        out_a, out_ap = np.empty_like(alpha), np.empty_like(alpha)
+        L.check(self._lib.dmf_update_alpha(self.ctx._h, self._h, _ptr(u), n_u, _ptr(alpha), _ptr(alpha_prev),
+                                           int(n_iter2), 0, sc, _ptr(out_a), _ptr(out_ap)),
+                "dmf_update_alpha")
+        return out_a, out_ap, sc[0], sc[1]
+
+
+class Solver:
+    """dmf_solver: state init (deconvolution.py:192-204) + stepping of the outer loop."""
+
+    def __init__(self, problem: Problem, u0, alpha0, mode=L.DMF_MODE_PARTIAL):
+        self.problem = problem
+        self._lib = problem._lib
+        u0 = np.ascontiguousarray(u0, dtype=np.float64).reshape(problem.N, -1)
+        alpha0 = np.ascontiguousarray(alpha0, dtype=np.float64)
+        self.n_u = int(u0.shape[1])
+        self.K = problem.n_c + self.n_u
+        if alpha0.shape != (self.K, problem.S):
+            raise ValueError(f"alpha shape {alpha0.shape} != {(self.K, problem.S)}")
+        h = C.c_void_p()
+        L.check(self._lib.dmf_solver_create(problem.ctx._h, problem._h, _ptr(u0), _ptr(alpha0), self.n_u,
+                                            int(mode), 0, C.byref(h)), "dmf_solver_create")
+        self._h = h
+
+    def step(self, n_outer: int, n_iter2: int, tol: float):
+        """Run up to n_outer outer iterations; returns (total iterations so far, converged)."""
+        it, conv = C.c_int64(), C.c_int()
+        L.check(self._lib.dmf_solver_step(self._h, int(n_outer), int(n_iter2), float(tol), C.byref(it),
+                                          C.byref(conv)), "dmf_solver_step")
+        return it.value, bool(conv.value)
+
+    def get(self):
+        """(u, alpha, cost, iterations) of the current iterate, as fresh host arrays."""
+        u = np.empty((self.problem.N, self.n_u), dtype=np.float64)
+        alpha = np.empty((self.K, self.problem.S), dtype=np.float64)
+        cost, it = C.c_double(), C.c_int64()
+        L.check(self._lib.dmf_solver_get(self._h, 0, _ptr(u), _ptr(alpha), C.byref(cost), C.byref(it)),
+                "dmf_solver_get")
+        return u, alpha, cost.value, it.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dmf_solver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -1,0 +1,138 @@
+/*
+ * demethify_hip.h — C-ABI of libdemethify_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for DeMethify's solver hot path.  The reference has no FFI layer: its
+ * seam is the set of Python callables that demethify/demethify.py:7, demethify/bootstrap.py:6
+ * and demethify/ic.py:8 import from demethify/deconvolution.py.  Each entry point below names
+ * the reference callable it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns a dmf_status (0 = ok) and never
+ *     throws across the boundary; the caller allocates every output buffer.
+ *   - matrices are dense, C-order (row-major) float64; counts are int64 or float64 (flag).
+ *   - N = CpG rows, S = samples, n_c = known cell types, n_u = unknown, K = n_c + n_u.
+ *     V = meth_frequency (N x S), D = d_x / counts (N x S), Rt = R_trunc (N x n_c),
+ *     u (N x n_u), alpha (K x S; the LAST n_u rows are the unknown types).
+ *   - pointer arguments are host pointers unless the call's `flags` carries
+ *     DMF_PTR_DEVICE, in which case they are device pointers on the context's GPU
+ *     (e.g. PyTorch-ROCm `tensor.data_ptr()`); device inputs are borrowed, never freed.
+ *   - one context per GPU; a context is not thread-safe, independent contexts are.
+ *   - inputs are never mutated (reference convention, deconvolution.py:194-195).
+ */
+#ifndef DEMETHIFY_HIP_H
+#define DEMETHIFY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum dmf_status {
+    DMF_OK = 0,
+    DMF_ERR_BAD_ARG = 1,      /* null pointer, non-positive size, n_u < 1 where required ...   */
+    DMF_ERR_BAD_SHAPE = 2,    /* shapes inconsistent with the problem the handle was built for  */
+    DMF_ERR_HIP = 3,          /* a HIP runtime call failed; see dmf_last_error()                */
+    DMF_ERR_NONFINITE = 4,    /* NaN/Inf met in an input that the solver cannot propagate        */
+    DMF_ERR_UNSUPPORTED = 5,  /* size beyond what the kernels are built for (K > 64, ...)        */
+    DMF_ERR_NO_DEVICE = 6     /* no gfx950 device visible                                        */
+} dmf_status;
+
+enum {
+    DMF_PTR_DEVICE = 1,       /* data pointers of this call are device pointers                  */
+    DMF_COUNTS_F64 = 2        /* `counts` is float64 (default: int64, as pandas yields)          */
+};
+
+/* solver variants */
+enum {
+    DMF_MODE_PARTIAL = 0,     /* mdwbssmf_deconv: gradient of u taken at the extrapolated point  */
+    DMF_MODE_UNSUPERVISED = 1 /* unsupervised_deconv: gradient taken at the previous iterate     */
+};
+
+/* kernel families whose device time a profiling context accumulates (dmf_context_kernel_time) */
+enum {
+    DMF_KERNEL_ROWPASS = 0,   /* u-phase row pass (the dominant, HBM-streaming kernel)           */
+    DMF_KERNEL_GRAM = 1,      /* per-sample weighted Gram accumulation for the alpha phase        */
+    DMF_KERNEL_ALPHA = 2,     /* alpha inner loop + cost + scalar bookkeeping                    */
+    DMF_KERNEL_COST = 3,      /* streaming weighted cost                                         */
+    DMF_KERNEL_FAMILIES = 4
+};
+
+typedef struct dmf_context dmf_context;
+typedef struct dmf_problem dmf_problem;
+typedef struct dmf_solver dmf_solver;
+
+const char* dmf_status_string(int status);
+/* Text of the last HIP error seen by this thread's most recent failing call ("" if none). */
+const char* dmf_last_error(void);
+/* Library/ABI version, bumped when a signature changes. */
+int dmf_abi_version(void);
+
+/* ---- context: one per GPU -------------------------------------------------------------- */
+/* `stream` may be NULL (the context creates its own hipStream) or a hipStream_t to borrow. */
+int dmf_context_create(int device, void* stream, dmf_context** out);
+int dmf_context_destroy(dmf_context* ctx);
+int dmf_context_synchronize(dmf_context* ctx);
+/* Record HIP events around every launch of the kernel families above (costs a sync per read). */
+int dmf_context_set_profiling(dmf_context* ctx, int enabled);
+int dmf_context_kernel_time(dmf_context* ctx, int family, double* total_ms, int64_t* launches);
+int dmf_context_reset_kernel_time(dmf_context* ctx);
+/* Force the generic (any-shape) kernels instead of the shape-specialised ones; for tests. */
+int dmf_context_set_generic(dmf_context* ctx, int enabled);
+
+/* ---- problem: V, D, Rt resident in HBM + the per-problem constants ----------------------
+ * Replaces the (meth_frequency, d_x, R_trunc) argument triple every reference solver call
+ * takes (deconvolution.py:40,81,93,107,190).  n_c may be 0 (Rt ignored: unsupervised).
+ * Uploads (or borrows) the arrays, converts int64 counts to f64 once and precomputes
+ * max(D)^2 (deconvolution.py:197), ||Rt||_F^2 and the known-type blocks of the per-sample
+ * Gram matrices. */
+int dmf_problem_create(dmf_context* ctx, int64_t N, int64_t S, int64_t n_c,
+                       const double* V, const void* counts, const double* Rt,
+                       int flags, dmf_problem** out);
+/* Row-gathered copy for one bootstrap resample: rows idx[0..N) of V, D, Rt
+ * (bootstrap.py:28, sklearn.utils.resample applied to the three arrays).  idx: host int64. */
+int dmf_problem_gather(dmf_context* ctx, const dmf_problem* src, const int64_t* idx,
+                       int64_t n_idx, dmf_problem** out);
+int dmf_problem_destroy(dmf_problem* p);
+int dmf_problem_shape(const dmf_problem* p, int64_t* N, int64_t* S, int64_t* n_c);
+
+/* ---- single-function entry points (KAT parity of SURVEY.md section 8a rows 1-4) --------- */
+/* cost_f_w(y, R, alpha, d_x), deconvolution.py:15-17, with R = [Rt | u]. */
+int dmf_cost(dmf_context* ctx, const dmf_problem* p, const double* u, int64_t n_u,
+             const double* alpha, int flags, double* out_cost);
+/* projection_simplex_sort_2d(v, z), deconvolution.py:21-37; X and out are K x S. */
+int dmf_project_simplex(dmf_context* ctx, const double* X, int64_t K, int64_t S, double z,
+                        int flags, double* out);
+/* update_u(u, alpha, n_iter2, a1, l_w_, l_w, u_, meth_frequency, R_trunc, n_u, d_x),
+ * deconvolution.py:81-90 -> (u, u_, a1, l_w_).  mode selects the gradient point (row 6 of
+ * SURVEY.md section 8a).  scalars_io = {a1, l_w_prev, l_w} in, {a1, l_w_prev, l_w} out. */
+int dmf_update_u(dmf_context* ctx, const dmf_problem* p, const double* u, const double* u_prev,
+                 const double* alpha, int64_t n_u, int64_t n_iter2, int mode, int flags,
+                 double* scalars_io, double* out_u, double* out_u_prev);
+/* update_alpha(n_iter2, alpha, a2, l_h_, l_h, alpha_, R, d_x, meth_frequency),
+ * deconvolution.py:93-102 -> (alpha, alpha_, a2, l_h_), with R = [Rt | u].
+ * scalars_io = {a2, l_h_prev, l_h}. */
+int dmf_update_alpha(dmf_context* ctx, const dmf_problem* p, const double* u, int64_t n_u,
+                     const double* alpha, const double* alpha_prev, int64_t n_iter2, int flags,
+                     double* scalars_io, double* out_alpha, double* out_alpha_prev);
+
+/* ---- solver: the outer loop, resident on the device --------------------------------------
+ * mdwbssmf_deconv (deconvolution.py:190-223) / unsupervised_deconv's loop (:139-184).
+ * create = state init (:192-204); step = up to n_outer outer iterations, stopping early when
+ * |cf - cf_0| < tol (:220); get = copy out the current (u, alpha). */
+int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0,
+                      const double* alpha0, int64_t n_u, int mode, int flags, dmf_solver** out);
+int dmf_solver_step(dmf_solver* s, int64_t n_outer, int64_t n_iter2, double tol,
+                    int64_t* iters_done_total, int* converged);
+int dmf_solver_get(dmf_solver* s, int flags, double* out_u, double* out_alpha,
+                   double* out_cost, int64_t* out_iters);
+int dmf_solver_destroy(dmf_solver* s);
+/* One-shot convenience: create + step(n_iter1) + get + destroy. */
+int dmf_solve(dmf_context* ctx, const dmf_problem* p, const double* u0, const double* alpha0,
+              int64_t n_u, int mode, int64_t n_iter1, int64_t n_iter2, double tol, int flags,
+              double* out_u, double* out_alpha, double* out_cost, int64_t* out_iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEMETHIFY_HIP_H */
