@@ -1,0 +1,176 @@
+"""Per-function known-answer tests of the HIP path against the CPU oracle.
+All calls go through the C-ABI (demethify_amd.device / demethify_amd.deconvolution)."""
+import numpy as np
+import pytest
+
+from oracle import solver as osol
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # (N, S, n_c, n_u)
+    (257, 7, 6, 1), (1000, 64, 6, 2), (513, 100, 0, 4), (300, 10, 5, 3), (2048, 130, 12, 4), (129, 33, 3, 8),
+]
+
+
+def _problem(N, S, n_c, n_u, seed):
+    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=seed, depth=20)
+    rs = np.random.RandomState(seed + 100)
+    u = rs.uniform(size=(N, n_u))
+    alpha = rs.dirichlet(np.ones(n_c + n_u), S).T
+    return V, D, Rt, u, alpha, rs
+
+
+@pytest.mark.parametrize("N,S,n_c,n_u", SHAPES)
+def test_cost_matches_oracle(ctx, N, S, n_c, n_u):
+    from demethify_amd.device import Problem
+
+    V, D, Rt, u, alpha, _ = _problem(N, S, n_c, n_u, 1)
+    want = osol.weighted_cost(V, np.c_[Rt, u], alpha, D)
+    with Problem(ctx, V, D, Rt if n_c else None) as p:
+        got = p.cost(u, alpha)
+    assert abs(got - want) <= 1e-11 * abs(want)
+
+
+def test_cost_f_w_reference_signature(ctx):
+    from demethify_amd.deconvolution import cost_f_w
+
+    V, D, Rt, u, alpha, _ = _problem(400, 12, 4, 2, 2)
+    R = np.c_[Rt, u]
+    assert abs(cost_f_w(V, R, alpha, D) - osol.weighted_cost(V, R, alpha, D)) <= 1e-11 * osol.weighted_cost(V, R, alpha, D)
+    # float counts are accepted too (csv input without coverage column sets counts to 1)
+    Df = D.astype(np.float64)
+    assert abs(cost_f_w(V, R, alpha, Df) - osol.weighted_cost(V, R, alpha, Df)) <= 1e-11 * osol.weighted_cost(V, R, alpha, Df)
+
+
+@pytest.mark.parametrize("K,S", [(1, 5), (2, 64), (5, 10), (8, 65), (16, 256), (17, 3), (30, 70), (64, 9)])
+def test_projection_matches_oracle(ctx, K, S):
+    rs = np.random.RandomState(K * 1000 + S)
+    X = rs.randn(K, S) * rs.choice([0.05, 1.0, 20.0], size=(1, S))
+    X[:, 0] = 0.0  # all-equal column
+    if S > 2:
+        X[:, 1] = np.linspace(0, 1, K)  # already sorted ascending
+        X[:, 2] = X[0, 2]  # ties
+    got = ctx.project_simplex(X)
+    want = osol.simplex_project_columns(X)
+    assert np.abs(got - want).max() <= 1e-14 * max(1.0, np.abs(X).max())
+    assert np.allclose(got.sum(axis=0), 1.0, atol=1e-12)
+    got2 = ctx.project_simplex(X, z=2.5)
+    assert np.abs(got2 - osol.simplex_project_columns(X, z=2.5)).max() <= 1e-14 * max(1.0, np.abs(X).max())
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("N,S,n_c,n_u", SHAPES)
+def test_update_u_matches_oracle(ctx, N, S, n_c, n_u, generic):
+    """update_u with a NON-initial momentum state (a1 > 1, l_w_ != l_w, u_ != u)."""
+    from demethify_amd.device import Problem
+
+    V, D, Rt, u, alpha, rs = _problem(N, S, n_c, n_u, 3)
+    u_prev = np.clip(u + 0.05 * rs.randn(N, n_u), 0, 1)
+    d = float(D.max()) ** 2
+    l_w = np.linalg.norm(alpha[-n_u:]) ** 2 * d
+    a1, l_w_prev = 2.7, 0.8 * l_w
+    want = osol.u_phase(u, alpha, 5, a1, l_w_prev, l_w, u_prev, V, Rt, n_u, D)
+    ctx.set_generic(generic)
+    try:
+        with Problem(ctx, V, D, Rt if n_c else None) as p:
+            got = p.update_u(u, u_prev, alpha, 5, a1, l_w_prev, l_w)
+    finally:
+        ctx.set_generic(False)
+    assert np.abs(got[0] - want[0]).max() < 1e-11
+    assert np.abs(got[1] - want[1]).max() < 1e-11
+    assert got[2] == pytest.approx(want[2], rel=1e-15) and got[3] == want[3]
+
+
+def test_update_u_unsupervised_gradient_point(ctx):
+    """deconvolution.py:163: the unsupervised loop takes the gradient at the previous iterate."""
+    from demethify_amd import _lib as L
+    from demethify_amd.device import Problem
+
+    N, S, n_u = 700, 21, 3
+    V, D, _, u, alpha, rs = _problem(N, S, 0, n_u, 4)
+    u_prev = np.clip(u + 0.1 * rs.randn(N, n_u), 0, 1)
+    d = float(D.max()) ** 2
+    l_w = np.linalg.norm(alpha) ** 2 * d
+    a1, l_prev = 1.9, 1.3 * l_w
+    # oracle: two inner steps of the inline loop
+    uo, uo_prev, a, lp = u, u_prev, a1, l_prev
+    for _ in range(2):
+        a0 = a
+        a, beta = osol.momentum_step(a0, lp, l_w)
+        ut = uo + beta * (uo - uo_prev)
+        uo_prev = uo
+        uo = np.clip(ut + (D * (V - uo @ alpha)) @ alpha.T / l_w, 0, 1)
+        lp = l_w
+    for generic in (False, True):
+        ctx.set_generic(generic)
+        try:
+            with Problem(ctx, V, D, None) as p:
+                got = p.update_u(u, u_prev, alpha, 2, a1, l_prev, l_w, mode=L.DMF_MODE_UNSUPERVISED)
+        finally:
+            ctx.set_generic(False)
+        assert np.abs(got[0] - uo).max() < 1e-11
+        assert np.abs(got[1] - uo_prev).max() < 1e-11
+
+
+@pytest.mark.parametrize("N,S,n_c,n_u", SHAPES + [(500, 20, 10, 10), (400, 6, 5, 25)])
+def test_update_alpha_matches_oracle(ctx, N, S, n_c, n_u):
+    from demethify_amd.device import Problem
+
+    V, D, Rt, u, alpha, rs = _problem(N, S, n_c, n_u, 5)
+    alpha_prev = rs.dirichlet(np.ones(n_c + n_u), S).T
+    R = np.c_[Rt, u]
+    d = float(D.max()) ** 2
+    l_h = np.linalg.norm(R) ** 2 * d
+    a2, l_h_prev = 3.1, 1.1 * l_h
+    want = osol.alpha_phase(4, alpha, a2, l_h_prev, l_h, alpha_prev, R, D, V)
+    with Problem(ctx, V, D, Rt if n_c else None) as p:
+        got = p.update_alpha(u, alpha, alpha_prev, 4, a2, l_h_prev, l_h)
+    assert np.abs(got[0] - want[0]).max() < 1e-10
+    assert np.abs(got[1] - want[1]).max() < 1e-10
+    assert got[2] == pytest.approx(want[2], rel=1e-15) and got[3] == want[3]
+
+
+def test_reference_signatures_update_functions(ctx):
+    from demethify_amd import deconvolution as dd
+
+    V, D, Rt, u, alpha, rs = _problem(300, 9, 4, 2, 6)
+    R = np.c_[Rt, u]
+    d = float(D.max()) ** 2
+    l_w = np.linalg.norm(alpha[-2:]) ** 2 * d
+    l_h = np.linalg.norm(R) ** 2 * d
+    got = dd.update_u(u, alpha, 3, 1.0, l_w, l_w, u.copy(), V, Rt, 2, D)
+    want = osol.u_phase(u, alpha, 3, 1.0, l_w, l_w, u.copy(), V, Rt, 2, D)
+    assert np.abs(got[0] - want[0]).max() < 1e-11 and got[2] == pytest.approx(want[2])
+    got = dd.update_alpha(3, alpha, 1.0, l_h, l_h, alpha.copy(), R, D, V)
+    want = osol.alpha_phase(3, alpha, 1.0, l_h, l_h, alpha.copy(), R, D, V)
+    assert np.abs(got[0] - want[0]).max() < 1e-10
+    assert np.abs(dd.projection_simplex_sort_2d(alpha * 3) - osol.simplex_project_columns(alpha * 3)).max() < 1e-14
+
+
+def test_gather_rows_matches_fancy_indexing(ctx):
+    from demethify_amd.device import Problem
+
+    V, D, Rt, u, alpha, rs = _problem(600, 11, 5, 2, 7)
+    idx = osol.bootstrap_indices(11, 600)
+    with Problem(ctx, V, D, Rt) as p, p.gather(idx) as q:
+        got = q.cost(u, alpha)
+    want = osol.weighted_cost(V[idx], np.c_[Rt[idx], u], alpha, D[idx])
+    assert abs(got - want) <= 1e-11 * want
+
+
+def test_bad_arguments_raise(ctx):
+    from demethify_amd._lib import DemethifyHipError
+    from demethify_amd.device import Problem, Solver
+
+    V, D, Rt, u, alpha, _ = _problem(100, 5, 3, 2, 8)
+    with pytest.raises(ValueError):
+        Problem(ctx, V, D[:, :4], Rt)
+    with pytest.raises(ValueError):
+        Problem(ctx, np.where(V > 2, V, np.nan), D, Rt)
+    with Problem(ctx, V, D, Rt) as p:
+        with pytest.raises(ValueError):
+            Solver(p, u, alpha[:-1])
+        with pytest.raises(DemethifyHipError):
+            p.gather(np.array([0, 100]))

@@ -1,0 +1,78 @@
+"""CPU-only tests: host logic of the drop-in layer and the C-ABI's exported symbols."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import solver as osol
+
+from conftest import ROOT, read_props
+
+
+def test_library_exports_every_declared_symbol():
+    """The .so must load on a CPU-only box and export every function include/demethify_hip.h declares."""
+    from demethify_amd import _build, _lib
+
+    _build.build()
+    header = (ROOT / "include" / "demethify_hip.h").read_text()
+    declared = set(re.findall(r"\b(dmf_[a-z_0-9]+)\s*\(", header))
+    declared -= {"dmf_status"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().dmf_abi_version() == 1
+    assert _lib.load().dmf_status_string(2) == b"shape mismatch"
+
+
+def test_product_does_not_import_the_oracle():
+    for path in (ROOT / "demethify_amd").rglob("*.py"):
+        text = path.read_text()
+        assert "import oracle" not in text and "from oracle" not in text, path
+
+
+def test_wls_intercept_matches_reference_based_golden(toy):
+    from demethify_amd.init_func import wls_intercept
+
+    V, D, ref, _ = toy
+    alpha = np.concatenate([wls_intercept(D[:, k:k + 1] * V[:, k:k + 1], D[:, k:k + 1], ref) for k in range(10)], axis=1)
+    assert np.abs(alpha - read_props("output_ref_based")).max() < 1e-13
+    one = wls_intercept((D[:, 0] * V[:, 0]), D[:, 0], ref)
+    assert one.shape == (5,) and np.allclose(one, alpha[:, 0])
+
+
+@pytest.mark.parametrize("option", ["uniform_", "beta", "uniform"])
+def test_init_matches_oracle_rng_stream(toy, option):
+    from demethify_amd.deconvolution import init_BSSMF_md
+
+    V, D, ref, _ = toy
+    for seed in (1, [1], 7):
+        got = init_BSSMF_md(option, V, D, ref, 2, seed=seed)
+        want = osol.init_partial(option, V, D, ref, 2, seed=seed)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+    a = init_BSSMF_md(option, V, D, ref, 2, seed=1)[2]
+    b = init_BSSMF_md(option, V, D, ref, 2, seed=[1])[2]
+    assert not np.array_equal(a, b)  # --seed on the CLI yields a list: a different stream (demethify.py:43)
+
+
+def test_init_forces_uniform_underscore_when_more_unknowns_than_samples(toy):
+    from demethify_amd.deconvolution import init_BSSMF_md
+
+    V, D, ref, _ = toy
+    got = init_BSSMF_md("beta", V, D, ref, 11, seed=3)
+    want = osol.init_partial("uniform_", V, D, ref, 11, seed=3)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+
+
+def test_unsupervised_uniform_keeps_upstream_nameerror(toy):
+    from demethify_amd.deconvolution import _init_unsupervised
+
+    V, _, _, _ = toy
+    with pytest.raises(NameError):
+        _init_unsupervised("uniform", V, 2, 1)
+    u, a = _init_unsupervised("uniform_", V, 4, 1)
+    wu, wa = osol.init_unsupervised("uniform_", V, 4, 1)
+    assert np.array_equal(u, wu) and np.array_equal(a, wa)
