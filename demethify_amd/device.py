@@ -256,6 +256,12 @@ class Solver:
                 "dmf_solver_get")
         return u, alpha, cost.value, it.value
 
+    def get_cost(self):
+        """(cost, iterations) of the current iterate without copying u / alpha back."""
+        cost, it = C.c_double(), C.c_int64()
+        L.check(self._lib.dmf_solver_get(self._h, 0, None, None, C.byref(cost), C.byref(it)), "dmf_solver_get")
+        return cost.value, it.value
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.dmf_solver_destroy(self._h)
