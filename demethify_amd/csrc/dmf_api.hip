@@ -51,7 +51,7 @@ struct dmf_context {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool profiling = false;
-    bool force_generic = false;
+    int generic_level = 0;  // 0 best kernels, 1 no MFMA / specialised Gram, 2 schedule-faithful u steps
     double* scratch = nullptr;  // 4096 doubles of reduction scratch
     FamilyClock clocks[DMF_KERNEL_FAMILIES];
 };
@@ -71,7 +71,8 @@ struct dmf_solver {
     const dmf_problem* p = nullptr;
     int64_t n_u = 0;
     int mode = 0;
-    bool use_gram_u = true;
+    int u_path = 0;         // 0 MFMA, 1 Gram-form VALU, 2 schedule-faithful direct steps
+    bool use_gram_spec = false;
     double *u = nullptr, *u_prev = nullptr, *u_next = nullptr;
     double *alpha = nullptr, *alpha_prev = nullptr;
     double* gb = nullptr;
@@ -222,7 +223,10 @@ int enqueue_u_phase(dmf_solver* s, int n_iter2) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
     FamilyScope scope(ctx, DMF_KERNEL_ROWPASS);
-    if (s->use_gram_u) {
+    if (s->u_path == 0) {
+        HIP_TRY(dmf::launch_u_phase_mfma(p->V, p->D, p->Rt, s->alpha, s->u, s->u_prev, s->state, p->N,
+                                         (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
+    } else if (s->u_path == 1) {
         HIP_TRY(dmf::launch_u_phase_gram(p->V, p->D, p->Rt, s->alpha, s->u, s->u_prev, s->state, p->N,
                                          (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
     } else {
@@ -243,6 +247,14 @@ int enqueue_gram(dmf_solver* s) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
     FamilyScope scope(ctx, DMF_KERNEL_GRAM);
+    if (s->use_gram_spec) {
+        int ny = 0;
+        HIP_TRY(dmf::launch_gram_u(p->V, p->D, p->Rt, s->u, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, s->slab,
+                                   &s->state->done, &ny, ctx->stream));
+        HIP_TRY(dmf::launch_gram_reduce(s->slab, ny, s->n_jobs, (int)p->S, s->job_dst, s->gb, &s->state->done,
+                                        ctx->stream));
+        return DMF_OK;
+    }
     dmf::GramJobTable jobs{s->job_k, s->job_l, s->job_dst, s->n_jobs};
     HIP_TRY(dmf::launch_gram(p->V, p->D, p->Rt, s->u, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, jobs,
                              s->slab, s->slab_doubles, s->gb, &s->state->done, ctx->stream));
@@ -395,7 +407,8 @@ int dmf_context_reset_kernel_time(dmf_context* ctx) {
 
 int dmf_context_set_generic(dmf_context* ctx, int enabled) {
     if (ctx == nullptr) return DMF_ERR_BAD_ARG;
-    ctx->force_generic = enabled != 0;
+    if (enabled < 0 || enabled > 2) return DMF_ERR_BAD_ARG;
+    ctx->generic_level = enabled;
     return DMF_OK;
 }
 
@@ -520,8 +533,11 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     s->p = p;
     s->n_u = n_u;
     s->mode = mode;
-    s->use_gram_u = !ctx->force_generic && dmf::u_phase_gram_supported((int)S, (int)n_c, (int)n_u);
-    if (!s->use_gram_u && !dmf::u_step_direct_supported((int)S, (int)n_c, (int)n_u)) {
+    if (ctx->generic_level == 0 && dmf::u_phase_mfma_supported((int)S, (int)n_c, (int)n_u)) s->u_path = 0;
+    else if (ctx->generic_level <= 1 && dmf::u_phase_gram_supported((int)S, (int)n_c, (int)n_u)) s->u_path = 1;
+    else s->u_path = 2;
+    s->use_gram_spec = ctx->generic_level == 0 && dmf::gram_u_supported((int)n_c, (int)n_u);
+    if (s->u_path == 2 && !dmf::u_step_direct_supported((int)S, (int)n_c, (int)n_u)) {
         delete s;
         return DMF_ERR_UNSUPPORTED;
     }
@@ -538,12 +554,16 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
         }
     s->n_jobs = (int)hk.size();
     s->slab_doubles = dmf::gram_slab_doubles(N, (int)S, s->n_jobs);
+    if (s->use_gram_spec) {
+        const int64_t spec = dmf::gram_u_slab_doubles(N, (int)S, (int)n_c, (int)n_u);
+        if (spec > s->slab_doubles) s->slab_doubles = spec;
+    }
     const size_t un = (size_t)N * n_u * sizeof(double), an = (size_t)K * S * sizeof(double);
     const size_t gbn = (size_t)(K + 1) * (K + 2) / 2 * S * sizeof(double);
     const int nb_alpha = (int)((S + 63) / 64);
     hipError_t e = hipMalloc((void**)&s->u, un);
     if (e == hipSuccess) e = hipMalloc((void**)&s->u_prev, un);
-    if (e == hipSuccess && !s->use_gram_u) e = hipMalloc((void**)&s->u_next, un);
+    if (e == hipSuccess && s->u_path == 2) e = hipMalloc((void**)&s->u_next, un);
     if (e == hipSuccess) e = hipMalloc((void**)&s->alpha, an);
     if (e == hipSuccess) e = hipMalloc((void**)&s->alpha_prev, an);
     if (e == hipSuccess) e = hipMalloc((void**)&s->gb, gbn);
@@ -593,7 +613,7 @@ int dmf_solver_step(dmf_solver* s, int64_t n_outer, int64_t n_iter2, double tol,
     DMF_TRY(fetch_state(s));
     // The device freezes the iterate once the stop test fires (every kernel checks state->done),
     // so the host may run ahead by `check_every` enqueued iterations without overshooting.
-    const int64_t check_every = s->use_gram_u ? 8 : 1;
+    const int64_t check_every = s->u_path != 2 ? 8 : 1;
     int64_t enqueued = 0;
     while (enqueued < n_outer && !s->h_state->done) {
         int64_t batch = n_outer - enqueued < check_every ? n_outer - enqueued : check_every;

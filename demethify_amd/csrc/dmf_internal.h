@@ -63,6 +63,14 @@ hipError_t launch_gram(const double* V, const double* D, const double* Rt, const
                        double* slab, int64_t slab_doubles, double* gb, const int* done_flag,
                        hipStream_t st);
 int64_t gram_slab_doubles(int64_t N, int S, int n_jobs);
+hipError_t launch_gram_reduce(const double* slab, int ny, int n_jobs, int S, const int* dst_row,
+                              double* gb, const int* done_flag, hipStream_t st);
+// shape-specialised one-pass Gram of the u-dependent entries (n_u <= 8, n_c <= 16); slab in job order
+bool gram_u_supported(int n_c, int n_u);
+int64_t gram_u_slab_doubles(int64_t N, int S, int n_c, int n_u);
+hipError_t launch_gram_u(const double* V, const double* D, const double* Rt, const double* u, int64_t N,
+                         int S, int n_c, int n_u, double* slab, const int* done_flag, int* ny_out,
+                         hipStream_t st);
 
 // u phase, Gram form (n_u <= 8): all n_iter2 inner iterations in one launch
 hipError_t launch_u_phase_gram(const double* V, const double* D, const double* Rt,
@@ -70,6 +78,11 @@ hipError_t launch_u_phase_gram(const double* V, const double* D, const double* R
                                const SolverState* state, int64_t N, int S, int n_c, int n_u,
                                int n_iter2, int mode, hipStream_t st);
 bool u_phase_gram_supported(int S, int n_c, int n_u);
+// u phase on the FP64 matrix cores (n_u <= 8, n_c <= 16, S <= 512)
+bool u_phase_mfma_supported(int S, int n_c, int n_u);
+hipError_t launch_u_phase_mfma(const double* V, const double* D, const double* Rt, const double* alpha,
+                               double* u, double* u_prev, const SolverState* state, int64_t N, int S,
+                               int n_c, int n_u, int n_iter2, int mode, hipStream_t st);
 // u phase, schedule-faithful fallback: ONE inner iteration (index t) per launch
 hipError_t launch_u_step_direct(const double* V, const double* D, const double* Rt,
                                 const double* alpha, const double* u_cur, const double* u_prev,

@@ -253,6 +253,13 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
     gb[(int64_t)dst_row[a] * S + s] = tot;
 }
 
+hipError_t launch_gram_reduce(const double* slab, int ny, int n_jobs, int S, const int* dst_row,
+                              double* gb, const int* done_flag, hipStream_t st) {
+    hipLaunchKernelGGL(k_gram_reduce, dim3((S + 255) / 256, n_jobs), dim3(256), 0, st, slab, ny, n_jobs, S,
+                       dst_row, gb, done_flag);
+    return hipGetLastError();
+}
+
 hipError_t launch_gram(const double* V, const double* D, const double* Rt, const double* u,
                        int64_t N, int S, int n_c, int n_u, GramJobTable jobs, double* slab,
                        int64_t slab_doubles, double* gb, const int* done_flag, hipStream_t st) {

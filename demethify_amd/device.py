@@ -64,9 +64,10 @@ class Context:
     def set_profiling(self, enabled: bool):
         L.check(self._lib.dmf_context_set_profiling(self._h, int(bool(enabled))), "dmf_context_set_profiling")
 
-    def set_generic(self, enabled: bool):
-        """Force the any-shape kernels (used by tests to cover the fallback path)."""
-        L.check(self._lib.dmf_context_set_generic(self._h, int(bool(enabled))), "dmf_context_set_generic")
+    def set_generic(self, level: int):
+        """Kernel selection for tests: 0 fastest (MFMA row pass + one-pass Gram), 1 any-shape Gram-form
+        kernels, 2 schedule-faithful one-launch-per-inner-step kernels."""
+        L.check(self._lib.dmf_context_set_generic(self._h, int(level)), "dmf_context_set_generic")
 
     def reset_kernel_time(self):
         L.check(self._lib.dmf_context_reset_kernel_time(self._h), "dmf_context_reset_kernel_time")

@@ -77,8 +77,9 @@ int dmf_context_synchronize(dmf_context* ctx);
 int dmf_context_set_profiling(dmf_context* ctx, int enabled);
 int dmf_context_kernel_time(dmf_context* ctx, int family, double* total_ms, int64_t* launches);
 int dmf_context_reset_kernel_time(dmf_context* ctx);
-/* Force the generic (any-shape) kernels instead of the shape-specialised ones; for tests. */
-int dmf_context_set_generic(dmf_context* ctx, int enabled);
+/* Kernel selection, for tests: 0 = fastest available (FP64-MFMA row pass + one-pass Gram),
+ * 1 = any-shape Gram-form kernels without MFMA, 2 = schedule-faithful one-launch-per-inner-step. */
+int dmf_context_set_generic(dmf_context* ctx, int level);
 
 /* ---- problem: V, D, Rt resident in HBM + the per-problem constants ----------------------
  * Replaces the (meth_frequency, d_x, R_trunc) argument triple every reference solver call

@@ -60,7 +60,7 @@ def test_projection_matches_oracle(ctx, K, S):
     assert np.abs(got2 - osol.simplex_project_columns(X, z=2.5)).max() <= 1e-14 * max(1.0, np.abs(X).max())
 
 
-@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("generic", [0, 1, 2])
 @pytest.mark.parametrize("N,S,n_c,n_u", SHAPES)
 def test_update_u_matches_oracle(ctx, N, S, n_c, n_u, generic):
     """update_u with a NON-initial momentum state (a1 > 1, l_w_ != l_w, u_ != u)."""
@@ -77,7 +77,7 @@ def test_update_u_matches_oracle(ctx, N, S, n_c, n_u, generic):
         with Problem(ctx, V, D, Rt if n_c else None) as p:
             got = p.update_u(u, u_prev, alpha, 5, a1, l_w_prev, l_w)
     finally:
-        ctx.set_generic(False)
+        ctx.set_generic(0)
     assert np.abs(got[0] - want[0]).max() < 1e-11
     assert np.abs(got[1] - want[1]).max() < 1e-11
     assert got[2] == pytest.approx(want[2], rel=1e-15) and got[3] == want[3]
@@ -103,13 +103,13 @@ def test_update_u_unsupervised_gradient_point(ctx):
         uo_prev = uo
         uo = np.clip(ut + (D * (V - uo @ alpha)) @ alpha.T / l_w, 0, 1)
         lp = l_w
-    for generic in (False, True):
+    for generic in (0, 1, 2):
         ctx.set_generic(generic)
         try:
             with Problem(ctx, V, D, None) as p:
                 got = p.update_u(u, u_prev, alpha, 2, a1, l_prev, l_w, mode=L.DMF_MODE_UNSUPERVISED)
         finally:
-            ctx.set_generic(False)
+            ctx.set_generic(0)
         assert np.abs(got[0] - uo).max() < 1e-11
         assert np.abs(got[1] - uo_prev).max() < 1e-11
 

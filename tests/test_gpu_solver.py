@@ -58,7 +58,7 @@ CASES = [  # (N, S, n_c, n_u, T1)
 ]
 
 
-@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("generic", [0, 1, 2])
 @pytest.mark.parametrize("N,S,n_c,n_u,T1", CASES)
 def test_fixed_iteration_parity(ctx, N, S, n_c, n_u, T1, generic):
     """tol = 0 never satisfies the stop test: exactly T1 outer iterations on both sides."""
@@ -82,7 +82,7 @@ def test_fixed_iteration_parity(ctx, N, S, n_c, n_u, T1, generic):
         with Problem(ctx, V, D, Rt if n_c else None) as p:
             u, alpha, cost, iters = solve_problem(p, u0, a0, mode, T1, 20, 0.0, return_info=True)
     finally:
-        ctx.set_generic(False)
+        ctx.set_generic(0)
     assert iters == T1
     assert rel_err(alpha, wa) < TIGHT and np.abs(alpha - wa).max() < TIGHT
     assert np.abs(u - wu).max() < TIGHT
