@@ -61,6 +61,8 @@ struct dmf_problem {
     int64_t N = 0, S = 0, n_c = 0;
     double *V = nullptr, *D = nullptr, *Rt = nullptr;
     bool own_V = false, own_D = false, own_Rt = false;
+    double* Rtp = nullptr;       // R_trunc, rows zero-padded to a multiple of 4 doubles (== Rt if n_c % 4 == 0)
+    bool own_Rtp = false;
     double* consts = nullptr;    // device {dsq, ||Rt||^2, dmax}
     double h_consts[3] = {0, 0, 0};
     double* gb_known = nullptr;  // [(n_c+1)(n_c+2)/2][S]
@@ -177,6 +179,18 @@ int problem_finalize(dmf_problem* p) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (!std::isfinite(p->h_consts[2]) || !std::isfinite(p->h_consts[1])) return DMF_ERR_NONFINITE;
 
+    // padded copy of R_trunc for the shape-specialised kernels (aligned, branch-free row loads)
+    if (n_c > 0 && n_c <= 16) {
+        const int nct = (int)((n_c + 3) / 4 * 4);
+        if (nct == n_c) {
+            p->Rtp = p->Rt;
+        } else {
+            HIP_TRY(hipMalloc((void**)&p->Rtp, (size_t)N * nct * sizeof(double)));
+            p->own_Rtp = true;
+            HIP_TRY(dmf::launch_pad_rows(p->Rt, p->Rtp, N, (int)n_c, nct, ctx->stream));
+        }
+    }
+
     // known block: packed triangle over the extended indices (Rt_0..Rt_{n_c-1}, v)
     const int ext = (int)n_c + 1;
     const int n_jobs = ext * (ext + 1) / 2;
@@ -224,7 +238,7 @@ int enqueue_u_phase(dmf_solver* s, int n_iter2) {
     const dmf_problem* p = s->p;
     FamilyScope scope(ctx, DMF_KERNEL_ROWPASS);
     if (s->u_path == 0) {
-        HIP_TRY(dmf::launch_u_phase_mfma(p->V, p->D, p->Rt, s->alpha, s->u, s->u_prev, s->state, p->N,
+        HIP_TRY(dmf::launch_u_phase_mfma(p->V, p->D, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N,
                                          (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
     } else if (s->u_path == 1) {
         HIP_TRY(dmf::launch_u_phase_gram(p->V, p->D, p->Rt, s->alpha, s->u, s->u_prev, s->state, p->N,
@@ -249,7 +263,7 @@ int enqueue_gram(dmf_solver* s) {
     FamilyScope scope(ctx, DMF_KERNEL_GRAM);
     if (s->use_gram_spec) {
         int ny = 0;
-        HIP_TRY(dmf::launch_gram_u(p->V, p->D, p->Rt, s->u, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, s->slab,
+        HIP_TRY(dmf::launch_gram_u(p->V, p->D, p->Rtp, s->u, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, s->slab,
                                    &s->state->done, &ny, ctx->stream));
         HIP_TRY(dmf::launch_gram_reduce(s->slab, ny, s->n_jobs, (int)p->S, s->job_dst, s->gb, &s->state->done,
                                         ctx->stream));
@@ -503,6 +517,7 @@ int dmf_problem_destroy(dmf_problem* p) {
     if (p->own_V) hipFree(p->V);
     if (p->own_D) hipFree(p->D);
     if (p->own_Rt) hipFree(p->Rt);
+    if (p->own_Rtp) hipFree(p->Rtp);
     hipFree(p->consts);
     hipFree(p->gb_known);
     delete p;

@@ -49,6 +49,8 @@ hipError_t launch_max_f64(const double* x, int64_t n, double* scratch, double* o
 // sum of squares -> *out (device)
 hipError_t launch_sumsq_f64(const double* x, int64_t n, double* scratch, double* out,
                             const int* done_flag, hipStream_t st);
+hipError_t launch_pad_rows(const double* src, double* dst, int64_t n_rows, int width_src, int width_dst,
+                           hipStream_t st);
 hipError_t launch_gather_rows(const double* src, double* dst, const long long* idx, int64_t n_idx,
                               int64_t width, hipStream_t st);
 
@@ -65,10 +67,11 @@ hipError_t launch_gram(const double* V, const double* D, const double* Rt, const
 int64_t gram_slab_doubles(int64_t N, int S, int n_jobs);
 hipError_t launch_gram_reduce(const double* slab, int ny, int n_jobs, int S, const int* dst_row,
                               double* gb, const int* done_flag, hipStream_t st);
-// shape-specialised one-pass Gram of the u-dependent entries (n_u <= 8, n_c <= 16); slab in job order
+// shape-specialised one-pass Gram of the u-dependent entries (n_u <= 8, n_c <= 16); slab in job order.
+// Rtp = R_trunc with rows zero-padded to a multiple of 4 doubles (dmf_problem::Rtp).
 bool gram_u_supported(int n_c, int n_u);
 int64_t gram_u_slab_doubles(int64_t N, int S, int n_c, int n_u);
-hipError_t launch_gram_u(const double* V, const double* D, const double* Rt, const double* u, int64_t N,
+hipError_t launch_gram_u(const double* V, const double* D, const double* Rtp, const double* u, int64_t N,
                          int S, int n_c, int n_u, double* slab, const int* done_flag, int* ny_out,
                          hipStream_t st);
 
@@ -78,9 +81,9 @@ hipError_t launch_u_phase_gram(const double* V, const double* D, const double* R
                                const SolverState* state, int64_t N, int S, int n_c, int n_u,
                                int n_iter2, int mode, hipStream_t st);
 bool u_phase_gram_supported(int S, int n_c, int n_u);
-// u phase on the FP64 matrix cores (n_u <= 8, n_c <= 16, S <= 512)
+// u phase on the FP64 matrix cores (n_u <= 8, n_c <= 16, S <= 512); takes the padded Rtp as well
 bool u_phase_mfma_supported(int S, int n_c, int n_u);
-hipError_t launch_u_phase_mfma(const double* V, const double* D, const double* Rt, const double* alpha,
+hipError_t launch_u_phase_mfma(const double* V, const double* D, const double* Rtp, const double* alpha,
                                double* u, double* u_prev, const SolverState* state, int64_t N, int S,
                                int n_c, int n_u, int n_iter2, int mode, hipStream_t st);
 // u phase, schedule-faithful fallback: ONE inner iteration (index t) per launch

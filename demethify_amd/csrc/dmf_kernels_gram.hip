@@ -2,7 +2,7 @@
 // G_s = R^T diag(d_s) R and b_s = R^T (d_s * v_s) that involves the unknown profiles u).
 //
 // One pass over V and D per outer iteration.  Lane = sample column (coalesced 512 B per wave-row),
-// the row's R_trunc / u values are wave-uniform (scalar loads feeding v_fma_f64 directly), every
+// the row's R_trunc (padded copy Rtp) / u values are wave-uniform (scalar loads feeding v_fma_f64 directly), every
 // accumulator lives in registers for the whole row chunk:
 //     cross[k][j] += d * Rt_ik * u_ij        (NCT x NU)
 //     uu[j<=l]    += d * u_ij * u_il         (NU (NU+1) / 2)
@@ -17,7 +17,7 @@ constexpr int kGramRedChunk = 16;
 
 template <int NCT, int NU>
 __global__ __launch_bounds__(256) void k_gram_u(const double* __restrict__ V, const double* __restrict__ D,
-                                                const double* __restrict__ Rt, const double* __restrict__ u,
+                                                const double* __restrict__ Rtp, const double* __restrict__ u,
                                                 int64_t N, int S, int n_c, int64_t rows_per_chunk,
                                                 double* __restrict__ slab, const int* __restrict__ done_flag) {
     constexpr int NP = NU * (NU + 1) / 2;
@@ -36,10 +36,11 @@ __global__ __launch_bounds__(256) void k_gram_u(const double* __restrict__ V, co
 
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
     const int64_t r1 = r0 + rows_per_chunk < N ? r0 + rows_per_chunk : N;
-    for (int64_t i = r0 + wave; i < r1; i += 4) {
-        const double d = active ? D[i * S + sc] : 0.0;
-        const double v = V[i * S + sc];
-        const double* __restrict__ rt_row = Rt + i * n_c;
+
+    // Rtp is R_trunc with rows padded to NCT doubles (zeros): unconditional, 32-byte aligned scalar
+    // loads, and the padded accumulators simply stay zero.
+    auto accum_row = [&](int64_t i, double d, double v) {
+        const double* __restrict__ rt_row = Rtp + i * NCT;
         const double* __restrict__ u_row = u + i * NU;
         double uj[NU], t[NU];
 #pragma unroll
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void k_gram_u(const double* __restrict__ V, co
         }
 #pragma unroll
         for (int k = 0; k < NCT; ++k) {
-            const double rk = k < n_c ? rt_row[k] : 0.0;
+            const double rk = rt_row[k];
 #pragma unroll
             for (int j = 0; j < NU; ++j) acc[k * NU + j] = fma(rk, t[j], acc[k * NU + j]);
         }
@@ -59,7 +60,24 @@ __global__ __launch_bounds__(256) void k_gram_u(const double* __restrict__ V, co
             for (int j = 0; j <= l; ++j) acc[NCT * NU + tri(j, l)] = fma(t[j], uj[l], acc[NCT * NU + tri(j, l)]);
 #pragma unroll
         for (int j = 0; j < NU; ++j) acc[NCT * NU + NP + j] = fma(t[j], v, acc[NCT * NU + NP + j]);
+    };
+
+    // kRowUnroll rows in flight per wave: their V / D loads are issued together before the FMA work of
+    // the first one starts.  No predicates in the main loop (inactive lanes read a clamped column and
+    // never store); the ragged end of the chunk goes through the one-row tail loop.
+    constexpr int kRowUnroll = 4;
+    int64_t ib = r0 + wave;
+    for (; ib + 4 * (kRowUnroll - 1) < r1; ib += 4 * kRowUnroll) {
+        double dd[kRowUnroll], vv[kRowUnroll];
+#pragma unroll
+        for (int x = 0; x < kRowUnroll; ++x) {
+            dd[x] = D[(ib + 4 * x) * S + sc];
+            vv[x] = V[(ib + 4 * x) * S + sc];
+        }
+#pragma unroll
+        for (int x = 0; x < kRowUnroll; ++x) accum_row(ib + 4 * x, dd[x], vv[x]);
     }
+    for (; ib < r1; ib += 4) accum_row(ib, D[ib * S + sc], V[ib * S + sc]);
 
     // cross-wave sum in fixed order, kGramRedChunk accumulators at a time, then scatter to the
     // slab in the solver's job order
@@ -76,8 +94,6 @@ __global__ __launch_bounds__(256) void k_gram_u(const double* __restrict__ V, co
         if (wave == 0 && active) {
 #pragma unroll
             for (int p = 0; p < kGramRedChunk; ++p) {
-                constexpr int dummy = 0;
-                (void)dummy;
                 const int a = c0 + p;
                 if (a < NACC) {
                     // accumulator a -> (k, l) -> job index

@@ -13,6 +13,7 @@
 // Layout facts used (verified on hardware with tools/mfma_probe.hip):
 //   A[i][k]: lane (i = l & 15, k = l >> 4);  B[k][j]: lane (k = l >> 4, j = l & 15);
 //   C/D register r of lane l = C[(l >> 4) + 4 r][l & 15].
+// `Rt` here is the problem's padded copy of R_trunc: row stride 4 * NKC doubles, zero pad columns.
 #include "dmf_device.h"
 #include "dmf_internal.h"
 
@@ -24,7 +25,35 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 constexpr int kStripsPerWave = 4;  // 16-sample strips owned by one wave (64 samples)
 constexpr int kMfmaMaxWaves = 8;   // S <= 512 on this path
 
-template <int NKC, int NU>
+// Broadcast of lane (group base + L)'s value inside aligned groups of NU lanes.  NU = 2 / 4 use a DPP
+// quad permute (no LDS traffic); other group sizes go through ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int NU, int L>
+__device__ __forceinline__ double group_bcast(double x, int lane0) {
+    if constexpr (NU == 1) return x;
+    else if constexpr (NU == 2) return dpp_quad<(L) | (L << 2) | ((2 + L) << 4) | ((2 + L) << 6)>(x);
+    else if constexpr (NU == 4) return dpp_quad<L | (L << 2) | (L << 4) | (L << 6)>(x);
+    else return __shfl(x, lane0 + L, 64);
+}
+
+template <int NU, int L = 0>
+__device__ __forceinline__ double grad_row(double g, double base, const double (&Mrow)[NU], int lane0) {
+    if constexpr (L < NU) {
+        g = fma(-group_bcast<NU, L>(base, lane0), Mrow[L], g);
+        return grad_row<NU, L + 1>(g, base, Mrow, lane0);
+    } else {
+        return g;
+    }
+}
+
+// VEC: S % 4 == 0, so a lane's four samples are contiguous, 32-byte aligned and all in range.
+template <int NKC, int NU, bool VEC>
 __global__ __launch_bounds__(512) void k_u_phase_mfma(
     const double* __restrict__ V, const double* __restrict__ D, const double* __restrict__ Rt,
     const double* __restrict__ alpha, double* __restrict__ u, double* __restrict__ u_prev,
@@ -32,7 +61,7 @@ __global__ __launch_bounds__(512) void k_u_phase_mfma(
     constexpr int NP = NU * (NU + 1) / 2;
     constexpr int NMT = (NP + 15) / 16;  // 16-row tiles of the pair matrix
     constexpr int NV = NU + NP;
-    extern __shared__ double red[];      // [2][NW][NV][16]
+    extern __shared__ double lds_dyn[];  // beta[n_iter2] then red[2][NW][NV][16]
     if (state->done) return;
 
     const int NW = blockDim.x >> 6;
@@ -40,57 +69,125 @@ __global__ __launch_bounds__(512) void k_u_phase_mfma(
     const int lane = threadIdx.x & 63;
     const int m16 = lane & 15, q = lane >> 4;
     const double* __restrict__ A2 = alpha + (int64_t)n_c * S;
+    double* __restrict__ beta_tab = lds_dyn;
+    double* __restrict__ red = lds_dyn + ((n_iter2 + 1) & ~1);
 
-    // ---- per-wave constant A operands -------------------------------------------------------
+    // momentum coefficients of the n_iter2 inner steps (deconvolution.py:83-85): same for every row
+    if (threadIdx.x == 0) {
+        double a1 = state->a1, lw_prev = state->l_w_prev;
+        const double lw = state->l_w;
+        for (int t2 = 0; t2 < n_iter2; ++t2) {
+            double beta;
+            momentum_step(a1, lw_prev, lw, beta);
+            beta_tab[t2] = beta;
+            lw_prev = lw;
+        }
+    }
+    const double inv_lw = 1.0 / state->l_w;  // x / l_w as x * (1 / l_w): <= 1 ulp from the division
+
+    // ---- per-wave constant A operands (zero for samples >= S and types >= n_c / n_u) ----------
     double a1op[kStripsPerWave][NKC > 0 ? NKC : 1];
     double a2op[kStripsPerWave][4];
     double pop[kStripsPerWave][NMT][4];
-    bool strip_ok[kStripsPerWave];
+    int col0[kStripsPerWave];  // first of this lane's four samples in strip t (clamped into range)
 #pragma unroll
     for (int t = 0; t < kStripsPerWave; ++t) {
         const int s0 = (wave * kStripsPerWave + t) * 16;
-        strip_ok[t] = s0 < S;
         // first product: m <-> sample s0 + 4 (m & 3) + (m >> 2), k <-> known type 4 kc + q
         const int s_e = s0 + 4 * (m16 & 3) + (m16 >> 2);
+        const int s_ec = s_e < S ? s_e : S - 1;
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) {
             const int kk = kc * 4 + q;
-            a1op[t][kc] = (kk < n_c && s_e < S) ? -alpha[(int64_t)kk * S + s_e] : 0.0;
+            const double keep = (kk < n_c && s_e < S) ? -1.0 : 0.0;
+            a1op[t][kc] = keep * alpha[(int64_t)(kk < n_c ? kk : 0) * S + s_ec];
+        }
+        int jp[NMT], lp[NMT];
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+            const int p = mt * 16 + m16;
+            int l = 0;
+            while ((l + 1) * (l + 2) / 2 <= p) ++l;
+            jp[mt] = p < NP ? p - l * (l + 1) / 2 : 0;
+            lp[mt] = p < NP ? l : 0;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int s = s0 + 4 * q + r;  // k-step r: k = q <-> sample s0 + 4 q + r
-            a2op[t][r] = (m16 < NU && s < S) ? A2[(int64_t)m16 * S + s] : 0.0;
+            const int sc = s < S ? s : S - 1;
+            const double keep2 = (m16 < NU && s < S) ? 1.0 : 0.0;
+            a2op[t][r] = keep2 * A2[(int64_t)(m16 < NU ? m16 : 0) * S + sc];
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) {
-                const int p = mt * 16 + m16;
-                double val = 0.0;
-                if (p < NP && s < S) {
-                    int l = 0;
-                    while ((l + 1) * (l + 2) / 2 <= p) ++l;
-                    const int j = p - l * (l + 1) / 2;
-                    val = A2[(int64_t)j * S + s] * A2[(int64_t)l * S + s];
-                }
-                pop[t][mt][r] = val;
+                const double keepp = (mt * 16 + m16 < NP && s < S) ? 1.0 : 0.0;
+                pop[t][mt][r] = keepp * (A2[(int64_t)jp[mt] * S + sc] * A2[(int64_t)lp[mt] * S + sc]);
             }
         }
+        const int c = s0 + 4 * q;
+        col0[t] = VEC ? (c < S ? c : 0) : c;
+    }
+    __syncthreads();  // beta_tab visible
+
+    const int64_t nblk = (N + 15) / 16;
+    // Loads are unconditional from clamped addresses: out-of-range samples meet zero A operands and
+    // out-of-range rows only feed output columns that are never read, so no masking is needed.
+    auto load_strip = [&](int64_t rowc, int t, v4d& e, v4d& d) {
+        const double* __restrict__ vp = V + rowc * S;
+        const double* __restrict__ dp = D + rowc * S;
+        if constexpr (VEC) {
+            const v2d v01 = *reinterpret_cast<const v2d*>(vp + col0[t]);
+            const v2d v23 = *reinterpret_cast<const v2d*>(vp + col0[t] + 2);
+            const v2d d01 = *reinterpret_cast<const v2d*>(dp + col0[t]);
+            const v2d d23 = *reinterpret_cast<const v2d*>(dp + col0[t] + 2);
+            e = v4d{v01.x, v01.y, v23.x, v23.y};
+            d = v4d{d01.x, d01.y, d23.x, d23.y};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = col0[t] + r < S ? col0[t] + r : S - 1;
+                e[r] = vp[c];
+                d[r] = dp[c];
+            }
+        }
+    };
+    auto row_of = [&](int64_t blk) {
+        const int64_t row = blk * 16 + m16;
+        return row < N ? row : N - 1;
+    };
+
+    v4d nv[kStripsPerWave], nd[kStripsPerWave];
+    double nrt[NKC > 0 ? NKC : 1];
+    {
+        const int64_t rowc = row_of(blockIdx.x);
+#pragma unroll
+        for (int t = 0; t < kStripsPerWave; ++t) load_strip(rowc, t, nv[t], nd[t]);
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) nrt[kc] = Rt[rowc * (4 * NKC) + kc * 4 + q];
     }
 
-    const bool vec_ok = (S & 3) == 0;
-    const int64_t nblk = (N + 15) / 16;
-    double u2_acc = 0.0;
     int it = 0;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x, ++it) {
         const int64_t row0 = blk * 16;
-        const int64_t row = row0 + m16;
-        const bool row_ok = row < N;
-        const int64_t rowc = row_ok ? row : N - 1;
+        const int64_t nxt = blk + gridDim.x < nblk ? blk + gridDim.x : blk;
+        const int64_t rowc_n = row_of(nxt);
+
+        // the wave that will run this block's inner iterations fetches its u / u_ now (first pass)
+        constexpr int RPW = 64 / NU;  // rows per pass of the inner-iteration phase
+        const int rl = lane / NU, j = lane - rl * NU;
+        const bool my_turn = wave == it % NW;
+        const bool ok0 = rl < RPW && rl < 16 && row0 + rl < N;
+        double uu0 = 0.0, up0 = 0.0;
+        if (my_turn) {
+            const int64_t gi0 = ok0 ? (row0 + rl) * NU + j : 0;
+            uu0 = u[gi0];
+            up0 = u_prev[gi0];
+        }
 
         double rtop[NKC > 0 ? NKC : 1];
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) {
-            const int kk = kc * 4 + q;
-            rtop[kc] = (row_ok && kk < n_c) ? Rt[rowc * n_c + kk] : 0.0;
+            rtop[kc] = nrt[kc];  // B operand of the first product: Rt^T[k = 4 kc + q][n = row]
+            nrt[kc] = Rt[rowc_n * (4 * NKC) + kc * 4 + q];
         }
         v4d cacc = {0.0, 0.0, 0.0, 0.0};
         v4d macc[NMT];
@@ -99,43 +196,20 @@ __global__ __launch_bounds__(512) void k_u_phase_mfma(
 
 #pragma unroll
         for (int t = 0; t < kStripsPerWave; ++t) {
-            if (strip_ok[t]) {
-                const int s0 = (wave * kStripsPerWave + t) * 16 + 4 * q;
-                const double* __restrict__ vp = V + rowc * S + s0;
-                const double* __restrict__ dp = D + rowc * S + s0;
-                v4d e, d;
-                if (vec_ok) {
-                    if (s0 < S) {
-                        const v2d v01 = *reinterpret_cast<const v2d*>(vp);
-                        const v2d v23 = *reinterpret_cast<const v2d*>(vp + 2);
-                        const v2d d01 = *reinterpret_cast<const v2d*>(dp);
-                        const v2d d23 = *reinterpret_cast<const v2d*>(dp + 2);
-                        e = v4d{v01.x, v01.y, v23.x, v23.y};
-                        d = v4d{d01.x, d01.y, d23.x, d23.y};
-                    } else {
-                        e = v4d{0.0, 0.0, 0.0, 0.0};
-                        d = e;
-                    }
-                } else {
+            v4d e = nv[t];
+            const v4d d = nd[t];
+            load_strip(rowc_n, t, nv[t], nd[t]);  // prefetch the next row block's strip t ...
+            __builtin_amdgcn_sched_barrier(0);    // ... and keep it in front of this strip's MFMAs
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool ok = s0 + r < S;
-                        e[r] = ok ? vp[r] : 0.0;
-                        d[r] = ok ? dp[r] : 0.0;
-                    }
-                }
-                if (!row_ok) d = v4d{0.0, 0.0, 0.0, 0.0};
+            for (int kc = 0; kc < NKC; ++kc)
+                e = __builtin_amdgcn_mfma_f64_16x16x4f64(a1op[t][kc], rtop[kc], e, 0, 0, 0);
+            const v4d w = d * e;
 #pragma unroll
-                for (int kc = 0; kc < NKC; ++kc)
-                    e = __builtin_amdgcn_mfma_f64_16x16x4f64(a1op[t][kc], rtop[kc], e, 0, 0, 0);
-                const v4d w = d * e;
+            for (int r = 0; r < 4; ++r) {
+                cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2op[t][r], w[r], cacc, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2op[t][r], w[r], cacc, 0, 0, 0);
-#pragma unroll
-                    for (int mt = 0; mt < NMT; ++mt)
-                        macc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(pop[t][mt][r], d[r], macc[mt], 0, 0, 0);
-                }
+                for (int mt = 0; mt < NMT; ++mt)
+                    macc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(pop[t][mt][r], d[r], macc[mt], 0, 0, 0);
             }
         }
 
@@ -154,10 +228,9 @@ __global__ __launch_bounds__(512) void k_u_phase_mfma(
         __syncthreads();
 
         // ---- row-local inner iterations by one wave (round robin), lane = (row, unknown j)
-        if (wave == it % NW) {
-            constexpr int RPW = 64 / NU;  // rows per pass
+        if (my_turn) {
             const double* __restrict__ all = red + ((size_t)(it & 1) * NW * NV) * 16;
-            const int rl = lane / NU, j = lane - rl * NU;
+            const int lane0 = lane - j;
             for (int pass0 = 0; pass0 < 16; pass0 += RPW) {
                 const int rloc = pass0 + rl;
                 const bool ok = rl < RPW && rloc < 16 && row0 + rloc < N;
@@ -175,32 +248,23 @@ __global__ __launch_bounds__(512) void k_u_phase_mfma(
                     }
                 }
                 const int64_t gi = ok ? (row0 + rloc) * NU + j : 0;
-                double uu = ok ? u[gi] : 0.0;
-                double up = ok ? u_prev[gi] : 0.0;
-                double a1 = state->a1, lw_prev = state->l_w_prev;
-                const double lw = state->l_w;
-                const int lane0 = lane - j;
+                double uu = pass0 == 0 ? uu0 : u[gi];
+                double up = pass0 == 0 ? up0 : u_prev[gi];
                 for (int t2 = 0; t2 < n_iter2; ++t2) {
-                    double beta;
-                    momentum_step(a1, lw_prev, lw, beta);
+                    const double beta = beta_tab[t2];
                     const double ut = uu + beta * (uu - up);
                     const double base = mode == 1 ? uu : ut;  // deconvolution.py:163 vs :88
                     up = uu;
-                    double g = cj;
-#pragma unroll
-                    for (int l = 0; l < NU; ++l) g = fma(-__shfl(base, lane0 + l, 64), Mrow[l], g);
-                    uu = fmin(fmax(ut + g / lw, 0.0), 1.0);
-                    lw_prev = lw;
+                    const double g = grad_row<NU>(cj, base, Mrow, lane0);
+                    uu = fmin(fmax(fma(g, inv_lw, ut), 0.0), 1.0);
                 }
                 if (ok) {
                     u[gi] = uu;
                     u_prev[gi] = up;
-                    u2_acc = fma(uu, uu, u2_acc);
                 }
             }
         }
     }
-    (void)u2_acc;
 }
 
 bool u_phase_mfma_supported(int S, int n_c, int n_u) {
@@ -214,16 +278,24 @@ static hipError_t launch_u_mfma_t(const double* V, const double* D, const double
     constexpr int NV = NU + NU * (NU + 1) / 2;
     const int nstrips = (S + 15) / 16;
     const int NW = (nstrips + kStripsPerWave - 1) / kStripsPerWave;
-    const size_t lds = (size_t)2 * NW * NV * 16 * sizeof(double);
+    const size_t lds = ((size_t)((n_iter2 + 1) & ~1) + (size_t)2 * NW * NV * 16) * sizeof(double);
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    const bool vec = (S & 3) == 0;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_u_phase_mfma<NKC, NU>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = vec ? hipFuncSetAttribute((const void*)k_u_phase_mfma<NKC, NU, true>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                           : hipFuncSetAttribute((const void*)k_u_phase_mfma<NKC, NU, false>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int64_t nblk = (N + 15) / 16;
     const int64_t grid = nblk < 768 ? nblk : 768;
-    hipLaunchKernelGGL((k_u_phase_mfma<NKC, NU>), dim3((unsigned)grid), dim3(NW * 64), lds, st, V, D, Rt, alpha, u,
-                       u_prev, state, N, S, n_c, n_iter2, mode);
+    if (vec)
+        hipLaunchKernelGGL((k_u_phase_mfma<NKC, NU, true>), dim3((unsigned)grid), dim3(NW * 64), lds, st, V, D, Rt,
+                           alpha, u, u_prev, state, N, S, n_c, n_iter2, mode);
+    else
+        hipLaunchKernelGGL((k_u_phase_mfma<NKC, NU, false>), dim3((unsigned)grid), dim3(NW * 64), lds, st, V, D, Rt,
+                           alpha, u, u_prev, state, N, S, n_c, n_iter2, mode);
     return hipGetLastError();
 }
 

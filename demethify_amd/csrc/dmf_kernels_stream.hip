@@ -100,6 +100,27 @@ hipError_t launch_gather_rows(const double* src, double* dst, const long long* i
     return hipGetLastError();
 }
 
+// dst[r][0..width_dst) = src[r][0..width_src) followed by zeros (row-padded copy of R_trunc)
+__global__ __launch_bounds__(256) void k_pad_rows(const double* __restrict__ src, double* __restrict__ dst,
+                                                  int64_t n_rows, int width_src, int width_dst) {
+    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = n_rows * width_dst, stride = (int64_t)gridDim.x * 256;
+    for (; e < total; e += stride) {
+        const int64_t r = e / width_dst;
+        const int c = (int)(e - r * width_dst);
+        dst[e] = c < width_src ? src[r * width_src + c] : 0.0;
+    }
+}
+
+hipError_t launch_pad_rows(const double* src, double* dst, int64_t n_rows, int width_src, int width_dst,
+                           hipStream_t st) {
+    if (n_rows <= 0 || width_dst <= 0) return hipSuccess;
+    int64_t b = (n_rows * width_dst + 255) / 256;
+    if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)b), dim3(256), 0, st, src, dst, n_rows, width_src, width_dst);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ direct weighted cost
 // sum_{i,s} d_is (v_is - sum_k R_ik alpha_ks)^2 with R = [Rt | u]; alpha staged in LDS when it fits.
 __global__ __launch_bounds__(256) void k_cost(const double* __restrict__ V, const double* __restrict__ D,
