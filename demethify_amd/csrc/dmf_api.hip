@@ -51,7 +51,8 @@ struct dmf_context {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool profiling = false;
-    int generic_level = 0;  // 0 best kernels, 1 no MFMA / specialised Gram, 2 schedule-faithful u steps
+    int generic_level = 0;  // 0 fused row pass, 1 any-shape Gram-form kernels, 2 schedule-faithful u steps,
+                            // 3 separate MFMA row pass + one-pass Gram (the pieces the fused kernel is made of)
     double* scratch = nullptr;  // 4096 doubles of reduction scratch
     FamilyClock clocks[DMF_KERNEL_FAMILIES];
 };
@@ -75,6 +76,8 @@ struct dmf_solver {
     int mode = 0;
     int u_path = 0;         // 0 MFMA, 1 Gram-form VALU, 2 schedule-faithful direct steps
     bool use_gram_spec = false;
+    bool use_fused = false;
+    double* u2_partials = nullptr;
     double *u = nullptr, *u_prev = nullptr, *u_next = nullptr;
     double *alpha = nullptr, *alpha_prev = nullptr;
     double* gb = nullptr;
@@ -287,6 +290,22 @@ int enqueue_alpha_phase(dmf_solver* s, int n_iter2) {
 int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
+    if (s->use_fused) {
+        int grid = 0;
+        {
+            FamilyScope scope(ctx, DMF_KERNEL_ROWPASS);
+            HIP_TRY(dmf::launch_rowpass_fused(p->V, p->D, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N,
+                                              (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, s->slab,
+                                              s->u2_partials, &grid, ctx->stream));
+        }
+        {
+            FamilyScope scope(ctx, DMF_KERNEL_GRAM);
+            HIP_TRY(dmf::launch_gram_reduce(s->slab, grid, s->n_jobs, (int)p->S, s->job_dst, s->gb,
+                                            &s->state->done, ctx->stream));
+        }
+        DMF_TRY(enqueue_alpha_phase(s, n_iter2));
+        return DMF_OK;
+    }
     DMF_TRY(enqueue_u_phase(s, n_iter2));
     HIP_TRY(dmf::launch_sumsq_f64(s->u, p->N * s->n_u, ctx->scratch, &s->state->u_norm2, &s->state->done,
                                   ctx->stream));
@@ -421,7 +440,7 @@ int dmf_context_reset_kernel_time(dmf_context* ctx) {
 
 int dmf_context_set_generic(dmf_context* ctx, int enabled) {
     if (ctx == nullptr) return DMF_ERR_BAD_ARG;
-    if (enabled < 0 || enabled > 2) return DMF_ERR_BAD_ARG;
+    if (enabled < 0 || enabled > 3) return DMF_ERR_BAD_ARG;
     ctx->generic_level = enabled;
     return DMF_OK;
 }
@@ -548,10 +567,12 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     s->p = p;
     s->n_u = n_u;
     s->mode = mode;
-    if (ctx->generic_level == 0 && dmf::u_phase_mfma_supported((int)S, (int)n_c, (int)n_u)) s->u_path = 0;
-    else if (ctx->generic_level <= 1 && dmf::u_phase_gram_supported((int)S, (int)n_c, (int)n_u)) s->u_path = 1;
+    const bool fast = ctx->generic_level == 0 || ctx->generic_level == 3;
+    if (fast && dmf::u_phase_mfma_supported((int)S, (int)n_c, (int)n_u)) s->u_path = 0;
+    else if (ctx->generic_level != 2 && dmf::u_phase_gram_supported((int)S, (int)n_c, (int)n_u)) s->u_path = 1;
     else s->u_path = 2;
-    s->use_gram_spec = ctx->generic_level == 0 && dmf::gram_u_supported((int)n_c, (int)n_u);
+    s->use_gram_spec = fast && dmf::gram_u_supported((int)n_c, (int)n_u);
+    s->use_fused = ctx->generic_level == 0 && dmf::rowpass_fused_supported((int)S, (int)n_c, (int)n_u);
     if (s->u_path == 2 && !dmf::u_step_direct_supported((int)S, (int)n_c, (int)n_u)) {
         delete s;
         return DMF_ERR_UNSUPPORTED;
@@ -573,6 +594,10 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
         const int64_t spec = dmf::gram_u_slab_doubles(N, (int)S, (int)n_c, (int)n_u);
         if (spec > s->slab_doubles) s->slab_doubles = spec;
     }
+    if (s->use_fused) {
+        const int64_t spec = dmf::rowpass_fused_slab_doubles(N, (int)S, (int)n_c, (int)n_u);
+        if (spec > s->slab_doubles) s->slab_doubles = spec;
+    }
     const size_t un = (size_t)N * n_u * sizeof(double), an = (size_t)K * S * sizeof(double);
     const size_t gbn = (size_t)(K + 1) * (K + 2) / 2 * S * sizeof(double);
     const int nb_alpha = (int)((S + 63) / 64);
@@ -584,6 +609,7 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     if (e == hipSuccess) e = hipMalloc((void**)&s->gb, gbn);
     if (e == hipSuccess) e = hipMalloc((void**)&s->slab, (size_t)s->slab_doubles * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&s->partials, (size_t)2 * nb_alpha * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->u2_partials, 1024 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&s->state, sizeof(SolverState));
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_state, sizeof(SolverState));
     if (e == hipSuccess) e = hipMalloc((void**)&s->job_k, s->n_jobs * sizeof(short));
@@ -667,6 +693,7 @@ int dmf_solver_destroy(dmf_solver* s) {
     hipFree(s->gb);
     hipFree(s->slab);
     hipFree(s->partials);
+    hipFree(s->u2_partials);
     hipFree(s->state);
     if (s->h_state) hipHostFree(s->h_state);
     hipFree(s->job_k);

@@ -60,7 +60,7 @@ def test_projection_matches_oracle(ctx, K, S):
     assert np.abs(got2 - osol.simplex_project_columns(X, z=2.5)).max() <= 1e-14 * max(1.0, np.abs(X).max())
 
 
-@pytest.mark.parametrize("generic", [0, 1, 2])
+@pytest.mark.parametrize("generic", [0, 1, 2, 3])
 @pytest.mark.parametrize("N,S,n_c,n_u", SHAPES)
 def test_update_u_matches_oracle(ctx, N, S, n_c, n_u, generic):
     """update_u with a NON-initial momentum state (a1 > 1, l_w_ != l_w, u_ != u)."""
@@ -103,7 +103,7 @@ def test_update_u_unsupervised_gradient_point(ctx):
         uo_prev = uo
         uo = np.clip(ut + (D * (V - uo @ alpha)) @ alpha.T / l_w, 0, 1)
         lp = l_w
-    for generic in (0, 1, 2):
+    for generic in (0, 1, 2, 3):
         ctx.set_generic(generic)
         try:
             with Problem(ctx, V, D, None) as p:

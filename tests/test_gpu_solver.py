@@ -58,7 +58,7 @@ CASES = [  # (N, S, n_c, n_u, T1)
 ]
 
 
-@pytest.mark.parametrize("generic", [0, 1, 2])
+@pytest.mark.parametrize("generic", [0, 1, 2, 3])
 @pytest.mark.parametrize("N,S,n_c,n_u,T1", CASES)
 def test_fixed_iteration_parity(ctx, N, S, n_c, n_u, T1, generic):
     """tol = 0 never satisfies the stop test: exactly T1 outer iterations on both sides."""
