@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--workload", default="headline_1e6x256_12+4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=40_000)
+    ap.add_argument("--kernels", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="kernel selection level (dmf_context_set_generic): 0 = fused row pass (default)")
     args = ap.parse_args()
 
     import torch
@@ -126,6 +128,7 @@ def main():
     torch.cuda.synchronize()
 
     ctx = Context(local_rank)
+    ctx.set_generic(args.kernels)
     problem = Problem(ctx, V, D, Rt)
     # restart k uses seed 1 + k; init drawn on the host in the reference's order
     rs = np.random.RandomState(1 + rank)

@@ -64,8 +64,9 @@ struct dmf_problem {
     bool own_V = false, own_D = false, own_Rt = false;
     double* Rtp = nullptr;       // R_trunc, rows zero-padded to a multiple of 4 doubles (== Rt if n_c % 4 == 0)
     bool own_Rtp = false;
-    double* consts = nullptr;    // device {dsq, ||Rt||^2, dmax}
-    double h_consts[3] = {0, 0, 0};
+    double* consts = nullptr;    // device {dsq, ||Rt||^2, dmax, max |D - f32(D)|}
+    double h_consts[4] = {0, 0, 0, 0};
+    bool d_f32_exact = false;    // every count survives a round trip through f32 (the fused tile stores D as f32)
     double* gb_known = nullptr;  // [(n_c+1)(n_c+2)/2][S]
 };
 
@@ -168,16 +169,18 @@ int export_array(dmf_context* ctx, const void* dev_src, size_t bytes, int flags,
 int problem_finalize(dmf_problem* p) {
     dmf_context* ctx = p->ctx;
     const int64_t N = p->N, S = p->S, n_c = p->n_c;
-    HIP_TRY(hipMalloc((void**)&p->consts, 3 * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&p->consts, 4 * sizeof(double)));
     HIP_TRY(dmf::launch_max_f64(p->D, N * S, ctx->scratch, p->consts + 2, ctx->stream));
     if (n_c > 0) {
         HIP_TRY(dmf::launch_sumsq_f64(p->Rt, N * n_c, ctx->scratch + 1024, p->consts + 1, nullptr, ctx->stream));
     } else {
         HIP_TRY(hipMemsetAsync(p->consts + 1, 0, sizeof(double), ctx->stream));
     }
-    HIP_TRY(hipMemcpyAsync(p->h_consts, p->consts, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(dmf::launch_f32_residual_max(p->D, N * S, ctx->scratch + 2048, p->consts + 3, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(p->h_consts, p->consts, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     p->h_consts[0] = p->h_consts[2] * p->h_consts[2];  // d = max(D)**2, deconvolution.py:197
+    p->d_f32_exact = p->h_consts[3] == 0.0;
     HIP_TRY(hipMemcpyAsync(p->consts, p->h_consts, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (!std::isfinite(p->h_consts[2]) || !std::isfinite(p->h_consts[1])) return DMF_ERR_NONFINITE;
@@ -572,7 +575,8 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     else if (ctx->generic_level != 2 && dmf::u_phase_gram_supported((int)S, (int)n_c, (int)n_u)) s->u_path = 1;
     else s->u_path = 2;
     s->use_gram_spec = fast && dmf::gram_u_supported((int)n_c, (int)n_u);
-    s->use_fused = ctx->generic_level == 0 && dmf::rowpass_fused_supported((int)S, (int)n_c, (int)n_u);
+    s->use_fused = ctx->generic_level == 0 && p->d_f32_exact &&
+                   dmf::rowpass_fused_supported((int)S, (int)n_c, (int)n_u);
     if (s->u_path == 2 && !dmf::u_step_direct_supported((int)S, (int)n_c, (int)n_u)) {
         delete s;
         return DMF_ERR_UNSUPPORTED;

@@ -46,6 +46,8 @@ struct GramJobTable {              // device arrays, one entry per accumulator
 hipError_t launch_convert_counts(const long long* src, double* dst, int64_t n, hipStream_t st);
 // max over a f64 array -> *out (device); scratch needs >= 1024 doubles
 hipError_t launch_max_f64(const double* x, int64_t n, double* scratch, double* out, hipStream_t st);
+// max |x - (double)(float)x| -> *out: 0 iff every element is exactly representable in f32
+hipError_t launch_f32_residual_max(const double* x, int64_t n, double* scratch, double* out, hipStream_t st);
 // sum of squares -> *out (device)
 hipError_t launch_sumsq_f64(const double* x, int64_t n, double* scratch, double* out,
                             const int* done_flag, hipStream_t st);

@@ -38,22 +38,24 @@ __device__ __forceinline__ void project_column(double (&x)[KMAX], int K, double 
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) srt[k] = k < K ? x[k] : -INFINITY;
     sort_desc<KMAX>(srt);
-    double run = 0.0, theta = 0.0;
-    bool any = false;
+    // rho = last j with srt_j - (cumsum_j - z) / (j + 1) > 0, tested as srt_j (j + 1) - (cumsum_j - z) > 0
+    // (same sign, no division in the scan); theta = (cumsum_rho - z) / (rho + 1) with ONE true division.
+    double run = 0.0, theta_num = 0.0, theta_den = 0.0;
     double last_shift = 0.0;
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
         if (j < K) {
             run += srt[j];
             const double shifted = run - z;
-            if (srt[j] - shifted / (double)(j + 1) > 0.0) {
-                theta = shifted / (double)(j + 1);
-                any = true;
+            if (fma(srt[j], (double)(j + 1), -shifted) > 0.0) {
+                theta_num = shifted;
+                theta_den = (double)(j + 1);
             }
             last_shift = shifted;
         }
     }
-    if (!any) theta = last_shift / 0.0;  // upstream: rho = -1 -> pi[-1] / 0 (only for non-finite input)
+    // no j qualified (non-finite input only): upstream takes rho = -1 -> pi[-1] / 0
+    const double theta = theta_den > 0.0 ? theta_num / theta_den : last_shift / 0.0;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) x[k] = k < K ? fmax(x[k] - theta, 0.0) : 0.0;
 }

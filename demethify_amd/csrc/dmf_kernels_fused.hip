@@ -24,8 +24,34 @@ namespace dmf {
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-constexpr int kTileRowDoubles = 66;  // 64 samples + 16 B pad: conflict-free b128 stores, b64 row reads
-constexpr int kTileDoubles = 16 * kTileRowDoubles;
+// Diagnostic build only (tools/fused_probe.hip defines DMF_STAMPS): per-wave cycle sums of the
+// kernel's segments go to a debug buffer of their own; the product build compiles none of it.
+#ifdef DMF_STAMPS
+#define DMF_STAMP_DECL unsigned long long st_last = dmf_stamp(), st_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DMF_STAMP(i) { const unsigned long long st_now = dmf_stamp(); st_seg[i] += st_now - st_last; st_last = st_now; }
+#define DMF_STAMP_FLUSH if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) stamps_out[((size_t)blockIdx.x * 16 + wave) * 8 + i_] = st_seg[i_];
+__device__ __forceinline__ unsigned long long dmf_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#else
+#define DMF_STAMP_DECL
+#define DMF_STAMP(i)
+#define DMF_STAMP_FLUSH
+#endif
+
+#define DMF_WAVES_PER_WG(NW) (3 * (NW))  // A team (NW waves) + C team (2 NW waves)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kTileRowDoubles = 66;  // V tile row: 64 samples + 16 B pad (f64)
+constexpr int kTileRowFloats = 68;   // D tile row: 64 samples + 16 B pad (f32: counts < 2^24 are exact)
+constexpr int kTileVBytes = 16 * kTileRowDoubles * 8;
+constexpr int kTileBytes = kTileVBytes + 16 * kTileRowFloats * 4;  // one column group, one buffer
 
 template <int CTRL>
 __device__ __forceinline__ double f_dpp_quad(double x) {
@@ -42,30 +68,38 @@ __device__ __forceinline__ double f_group_bcast(double x, int lane0) {
     else return __shfl(x, lane0 + L, 64);
 }
 
+// acc - sum_l base_l * Ms[l] over the NU lanes of a row group
 template <int NU, int L = 0>
-__device__ __forceinline__ double f_grad_row(double g, double base, const double (&Mrow)[NU], int lane0) {
+__device__ __forceinline__ double f_grad_row(double acc, double base, const double (&Ms)[NU], int lane0) {
     if constexpr (L < NU) {
-        g = fma(-f_group_bcast<NU, L>(base, lane0), Mrow[L], g);
-        return f_grad_row<NU, L + 1>(g, base, Mrow, lane0);
+        acc = fma(-f_group_bcast<NU, L>(base, lane0), Ms[L], acc);
+        return f_grad_row<NU, L + 1>(acc, base, Ms, lane0);
     } else {
-        return g;
+        return acc;
     }
 }
 
-// Team layout: a workgroup has 2 * NW waves (NW = ceil(S / 64)).  Waves [0, NW) form the A team,
-// waves [NW, 2 NW) the C team; A wave w and C wave NW + w own sample columns [64 w, 64 w + 64).
-// Step s of a workgroup overlaps, on every SIMD, the MFMA work of block s (A team) with the VALU
-// work of block s - 1 (C team):
-//   A team  write the prefetched V / D tile of block s to LDS buffer s & 1, issue the global loads of
-//           block s + 1 into registers, phase A (MFMA) -> partial c / M in LDS
+// Team layout: a workgroup has 3 NW waves (NW = ceil(S / 64) column groups of 64 samples).
+//   A team  waves [0, NW): A wave w owns column group w for phase A (MFMA) and takes turns at phase B
+//   C team  waves [NW, 3 NW): C wave (g, h) owns column group g and rows [8h, 8h + 8) of every block
+// so each SIMD holds one MFMA-bound wave and two VALU-bound waves (a lone wave issues FP64 VALU at half
+// rate).  Step s overlaps the A team's work on block s with the C team's work on block s - 1:
+//   A team  store the prefetched V / D tile of block s into LDS buffer s & 1, issue the global loads of
+//           block s + 1 into registers, phase A -> partial c / M in LDS
 //           -- barrier X --   phase B (one A wave, round robin) -> u rows to global + LDS   -- barrier Y --
-//   C team  phase C rows 0..7 of block s - 1 (buffer (s - 1) & 1)   -- X --   rows 8..15   -- Y --
+//   C team  phase C, first 4 of its rows of block s - 1   -- X --   last 4 rows   -- Y --
+// The alpha-derived MFMA A operands are re-read from an LDS copy of alpha for every strip (cheap) instead
+// of living in ~90 VGPRs, which is what lets three waves per SIMD fit.
 template <int NKC, int NU>
-__global__ __launch_bounds__(512) void k_rowpass_fused(
+__global__ __launch_bounds__(768) void k_rowpass_fused(
     const double* __restrict__ V, const double* __restrict__ D, const double* __restrict__ Rtp,
     const double* __restrict__ alpha, double* __restrict__ u, double* __restrict__ u_prev,
     const SolverState* __restrict__ state, int64_t N, int S, int n_c, int n_iter2, int mode,
-    double* __restrict__ slab, double* __restrict__ u2_partials) {
+    double* __restrict__ slab, double* __restrict__ u2_partials
+#ifdef DMF_STAMPS
+    , unsigned long long* __restrict__ stamps_out
+#endif
+    ) {
     constexpr int NCT = 4 * NKC;
     constexpr int NCTL = NCT > 0 ? NCT : 1;
     constexpr int NP = NU * (NU + 1) / 2;
@@ -75,21 +109,27 @@ __global__ __launch_bounds__(512) void k_rowpass_fused(
     extern __shared__ double lds_dyn[];
     if (state->done) return;
 
-    const int NW = blockDim.x >> 7;  // waves per team
+    const int NW = blockDim.x / 192;  // column groups
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const bool a_team = wave < NW;
-    const int cw = a_team ? wave : wave - NW;  // column group of this wave
-    const int wcol0 = cw * 64;
+    const int cidx = a_team ? 0 : wave - NW;
+    const int cg = a_team ? wave : cidx % NW;  // column group of this wave
+    const int wcol0 = cg * 64;
 
-    // LDS carve-up: beta[n_iter2 (even)] | ubuf[2][16][NU] | rtbuf[2][16][NCT] | red[NW][NV][16] |
-    //               tiles[2 buffers][NW column groups][V, D][16][kTileRowDoubles]
+    // LDS carve-up (doubles unless noted):
+    //   beta[n_iter2 (even)] | ubuf[2][16][NU] | rtbuf[2][16][NCT] | red[NW][NV][16] |
+    //   alds[(NCT + NU + 1) rows][AS]: -alpha_known (zero-padded to NCT rows), alpha_unk, one zero row |
+    //   tiles[2 buffers][NW groups]{ V f64 [16][66], D f32 [16][68] }
+    const int AS = NW * 64 + 2;  // alpha row stride in LDS
     double* __restrict__ beta_tab = lds_dyn;
     double* __restrict__ ubuf = beta_tab + ((n_iter2 + 1) & ~1);
     double* __restrict__ rtbuf = ubuf + 2 * 16 * NU;
     double* __restrict__ red = rtbuf + 2 * 16 * NCTL;
-    double* __restrict__ tiles = red + NW * NV * 16;
-    auto tile_of = [&](int buf) { return tiles + ((size_t)(buf * NW + cw) * 2) * kTileDoubles; };
+    double* __restrict__ alds = red + NW * NV * 16;
+    char* __restrict__ tiles = reinterpret_cast<char*>(alds + (size_t)(NCT + NU + 1) * AS);
+    auto tile_of = [&](int buf) { return tiles + (size_t)(buf * NW + cg) * kTileBytes; };
+    constexpr int ZROW = NCT + NU;  // index of the all-zero row of alds
 
     if (threadIdx.x == 0) {
         double a1 = state->a1, lw_prev = state->l_w_prev;
@@ -101,7 +141,16 @@ __global__ __launch_bounds__(512) void k_rowpass_fused(
             lw_prev = lw;
         }
     }
-    __syncthreads();  // beta_tab visible
+    for (int i = threadIdx.x; i < (NCT + NU + 1) * AS; i += blockDim.x) {
+        const int r = i / AS, c = i - r * AS;
+        double val = 0.0;
+        if (c < S) {
+            if (r < n_c) val = -alpha[(int64_t)r * S + c];
+            else if (r >= NCT && r < NCT + NU) val = alpha[(int64_t)(n_c + r - NCT) * S + c];
+        }
+        alds[i] = val;
+    }
+    __syncthreads();
 
     const int64_t nblk = (N + 15) / 16;
     const int nk = (int)((nblk - blockIdx.x + gridDim.x - 1) / gridDim.x);  // blocks of this workgroup
@@ -109,52 +158,34 @@ __global__ __launch_bounds__(512) void k_rowpass_fused(
     if (a_team) {
         // =========================== A team: phases A and B ===================================
         const int m16 = lane & 15, q = lane >> 4;
-        const double* __restrict__ A2 = alpha + (int64_t)n_c * S;
         const double inv_lw = 1.0 / state->l_w;  // x / l_w as x * (1 / l_w): <= 1 ulp from the division
-        double a1op[4][NKC > 0 ? NKC : 1];
-        double a2op[4][4];
-        double pop[4][NMT][4];
+        // LDS rows / columns this lane reads to form the MFMA A operands of a strip
+        const int e_col = wcol0 + 4 * (m16 & 3) + (m16 >> 2);   // + 16 t : first product, m <-> sample
+        const int k_col = wcol0 + 4 * q;                         // + 16 t + r : k-step r, k = q <-> sample
+        const int a2_row = m16 < NU ? NCT + m16 : ZROW;
+        int jp_row[NMT], lp_row[NMT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int s0 = wcol0 + t * 16;
-            const int s_e = s0 + 4 * (m16 & 3) + (m16 >> 2);
-            const int s_ec = s_e < S ? s_e : S - 1;
-#pragma unroll
-            for (int kc = 0; kc < NKC; ++kc) {
-                const int kk = kc * 4 + q;
-                const double keep = (kk < n_c && s_e < S) ? -1.0 : 0.0;
-                a1op[t][kc] = keep * alpha[(int64_t)(kk < n_c ? kk : 0) * S + s_ec];
-            }
-            int jp[NMT], lp[NMT];
-#pragma unroll
-            for (int mt = 0; mt < NMT; ++mt) {
-                const int p = mt * 16 + m16;
-                int l = 0;
-                while ((l + 1) * (l + 2) / 2 <= p) ++l;
-                jp[mt] = p < NP ? p - l * (l + 1) / 2 : 0;
-                lp[mt] = p < NP ? l : 0;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int s = s0 + 4 * q + r;
-                const int sc = s < S ? s : S - 1;
-                const double keep2 = (m16 < NU && s < S) ? 1.0 : 0.0;
-                a2op[t][r] = keep2 * A2[(int64_t)(m16 < NU ? m16 : 0) * S + sc];
-#pragma unroll
-                for (int mt = 0; mt < NMT; ++mt) {
-                    const double keepp = (mt * 16 + m16 < NP && s < S) ? 1.0 : 0.0;
-                    pop[t][mt][r] = keepp * (A2[(int64_t)jp[mt] * S + sc] * A2[(int64_t)lp[mt] * S + sc]);
-                }
-            }
+        for (int mt = 0; mt < NMT; ++mt) {
+            const int p = mt * 16 + m16;
+            int l = 0;
+            while ((l + 1) * (l + 2) / 2 <= p) ++l;
+            jp_row[mt] = p < NP ? NCT + p - l * (l + 1) / 2 : ZROW;
+            lp_row[mt] = p < NP ? NCT + l : ZROW;
         }
         // global -> register staging geometry: load i covers rows 2i, 2i+1; lane -> (row half, 2 samples)
         const int ld_row = lane >> 5;
         const int ld_col = (lane & 31) * 2;
         int ld_gcol = wcol0 + ld_col;
-        if (ld_gcol > S - 2) ld_gcol = S - 2;  // ragged last column group: clamped samples are never consumed
-        v2d pv[8], pd[8];
+        if (ld_gcol > S - 2) ld_gcol = S - 2;  // ragged last column group: clamped samples meet zero operands
+        v2d pv[8], pd[8];  // D stays f64 in flight: converting here would wait for the load right away
+        double nrt[NKC > 0 ? NKC : 1];
+        // (small loads first: vmcnt retires in order, so nothing issued after the 16 tile loads may be
+        // waited on before the next step)
         auto prefetch = [&](int64_t blk) {
             const int64_t r0 = blk * 16;
+            const int64_t rowc = r0 + m16 < N ? r0 + m16 : N - 1;
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) nrt[kc] = Rtp[rowc * NCT + kc * 4 + q];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int64_t gr = r0 + 2 * i + ld_row < N ? r0 + 2 * i + ld_row : N - 1;
@@ -164,41 +195,44 @@ __global__ __launch_bounds__(512) void k_rowpass_fused(
         };
         prefetch(blockIdx.x);
         double u2_acc = 0.0;
+        DMF_STAMP_DECL
 
         for (int s = 0; s <= nk; ++s) {
             if (s < nk) {
                 const int64_t blk = blockIdx.x + (int64_t)s * gridDim.x;
                 const int64_t row0 = blk * 16;
                 const int nvalid = N - row0 < 16 ? (int)(N - row0) : 16;
-                double* __restrict__ tileV = tile_of(s & 1);
-                double* __restrict__ tileD = tileV + kTileDoubles;
+                char* __restrict__ tile = tile_of(s & 1);
+                double* __restrict__ tileV = reinterpret_cast<double*>(tile);
+                float* __restrict__ tileD = reinterpret_cast<float*>(tile + kTileVBytes);
+                // the A team's path to barrier X (then phase B) is the workgroup's critical path; the C waves
+                // that share this SIMD's FP64 pipe fill whatever issue slots are left
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     *reinterpret_cast<v2d*>(tileV + (2 * i + ld_row) * kTileRowDoubles + ld_col) = pv[i];
-                    *reinterpret_cast<v2d*>(tileD + (2 * i + ld_row) * kTileRowDoubles + ld_col) = pd[i];
+                    *reinterpret_cast<v2f*>(tileD + (2 * i + ld_row) * kTileRowFloats + ld_col) =
+                        v2f{(float)pd[i].x, (float)pd[i].y};
                 }
-                if (s + 1 < nk) prefetch(blk + gridDim.x);
+                double rtop[NKC > 0 ? NKC : 1];
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc) {
+                    rtop[kc] = nrt[kc];  // B operand of the first product: Rt^T[k = 4 kc + q][n = row]
+                    if (wave == 0) rtbuf[((s & 1) * 16 + m16) * NCTL + kc * 4 + q] = rtop[kc];
+                }
                 // the wave that will run this block's inner iterations fetches its u / u_ now (first pass)
                 constexpr int RPW = 64 / NU;
                 const int rl = lane / NU, j = lane - rl * NU;
                 const bool my_turn = wave == s % NW;
-                double uu0 = 0.0, up0 = 0.0;
-                if (my_turn) {
-                    const bool ok0 = rl < RPW && rl < nvalid;
-                    const int64_t gi0 = ok0 ? (row0 + rl) * NU + j : 0;
-                    uu0 = u[gi0];
-                    up0 = u_prev[gi0];
-                }
-                double rtop[NKC > 0 ? NKC : 1];
-                {
-                    const int64_t rowc = row0 + m16 < N ? row0 + m16 : N - 1;
-#pragma unroll
-                    for (int kc = 0; kc < NKC; ++kc) {
-                        rtop[kc] = Rtp[rowc * NCT + kc * 4 + q];
-                        if (wave == 0) rtbuf[((s & 1) * 16 + m16) * NCTL + kc * 4 + q] = rtop[kc];
-                    }
-                }
+                // (unconditional on purpose: loads under a branch make the compiler's s_waitcnt placement
+                // pessimistic at the join and stall on the fresh prefetch)
+                const bool ok0 = rl < RPW && rl < nvalid;
+                const int64_t gi0 = ok0 ? (row0 + rl) * NU + j : 0;
+                const double uu0 = u[gi0];
+                const double up0 = u_prev[gi0];
+                prefetch(s + 1 < nk ? blk + gridDim.x : blk);
                 __builtin_amdgcn_wave_barrier();
+                DMF_STAMP(0)  // tile store + prefetch issue
 
                 // ---- phase A: MFMA contractions on the tile, row-on-lane layout
                 v4d cacc = {0.0, 0.0, 0.0, 0.0};
@@ -208,21 +242,23 @@ __global__ __launch_bounds__(512) void k_rowpass_fused(
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const double* __restrict__ tv = tileV + m16 * kTileRowDoubles + t * 16 + 4 * q;
-                    const double* __restrict__ td = tileD + m16 * kTileRowDoubles + t * 16 + 4 * q;
                     const v2d v01 = *reinterpret_cast<const v2d*>(tv), v23 = *reinterpret_cast<const v2d*>(tv + 2);
-                    const v2d d01 = *reinterpret_cast<const v2d*>(td), d23 = *reinterpret_cast<const v2d*>(td + 2);
+                    const v4f df = *reinterpret_cast<const v4f*>(tileD + m16 * kTileRowFloats + t * 16 + 4 * q);
                     v4d e = {v01.x, v01.y, v23.x, v23.y};
-                    const v4d d = {d01.x, d01.y, d23.x, d23.y};
+                    const v4d d = {(double)df.x, (double)df.y, (double)df.z, (double)df.w};
 #pragma unroll
                     for (int kc = 0; kc < NKC; ++kc)
-                        e = __builtin_amdgcn_mfma_f64_16x16x4f64(a1op[t][kc], rtop[kc], e, 0, 0, 0);
+                        e = __builtin_amdgcn_mfma_f64_16x16x4f64(alds[(kc * 4 + q) * AS + e_col + 16 * t], rtop[kc], e,
+                                                                 0, 0, 0);
                     const v4d w = d * e;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2op[t][r], w[r], cacc, 0, 0, 0);
+                        const int col = k_col + 16 * t + r;
+                        cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(alds[a2_row * AS + col], w[r], cacc, 0, 0, 0);
 #pragma unroll
                         for (int mt = 0; mt < NMT; ++mt)
-                            macc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(pop[t][mt][r], d[r], macc[mt], 0, 0, 0);
+                            macc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                alds[jp_row[mt] * AS + col] * alds[lp_row[mt] * AS + col], d[r], macc[mt], 0, 0, 0);
                     }
                 }
                 double* __restrict__ mine = red + (size_t)wave * NV * 16;
@@ -236,38 +272,49 @@ __global__ __launch_bounds__(512) void k_rowpass_fused(
                         if (p < NP) mine[(NU + p) * 16 + m16] = macc[mt][rr];
                     }
                 }
+                __builtin_amdgcn_s_setprio(0);
+                DMF_STAMP(1)  // phase A
                 __syncthreads();  // ---- barrier X
+                DMF_STAMP(2)  // wait at X
 
-                // ---- phase B: row-local inner iterations, lane = (row, unknown j)
+                // ---- phase B: row-local inner iterations, lane = (row, unknown j); c and M pre-scaled by 1/l_w
                 if (my_turn) {
+                    // the other waves of this SIMD keep the FP64 pipe busy with independent work; this
+                    // dependent chain sits on the workgroup's critical path, so it goes first
+                    __builtin_amdgcn_s_setprio(3);
                     const int lane0 = lane - j;
                     double* __restrict__ ub = ubuf + (s & 1) * 16 * NU;
                     for (int pass0 = 0; pass0 < 16; pass0 += RPW) {
                         const int rloc = pass0 + rl;
                         const bool ok = rl < RPW && rloc < nvalid;
                         const int rlc = rloc < 16 ? rloc : 15;
-                        double cj = 0.0, Mrow[NU];
+                        double cj = 0.0, Ms[NU];
 #pragma unroll
-                        for (int l = 0; l < NU; ++l) Mrow[l] = 0.0;
+                        for (int l = 0; l < NU; ++l) Ms[l] = 0.0;
                         for (int w = 0; w < NW; ++w) {
                             const double* __restrict__ part = red + (size_t)w * NV * 16;
                             cj += part[j * 16 + rlc];
 #pragma unroll
                             for (int l = 0; l < NU; ++l) {
                                 const int p = l <= j ? tri(l, j) : tri(j, l);
-                                Mrow[l] += part[(NU + p) * 16 + rlc];
+                                Ms[l] += part[(NU + p) * 16 + rlc];
                             }
                         }
+                        cj *= inv_lw;
+#pragma unroll
+                        for (int l = 0; l < NU; ++l) Ms[l] *= inv_lw;
                         const int64_t gi = ok ? (row0 + rloc) * NU + j : 0;
                         double uu = pass0 == 0 ? uu0 : u[gi];
                         double up = pass0 == 0 ? up0 : u_prev[gi];
+                        double beta = n_iter2 > 0 ? beta_tab[0] : 0.0;
                         for (int t2 = 0; t2 < n_iter2; ++t2) {
-                            const double beta = beta_tab[t2];
-                            const double ut = uu + beta * (uu - up);
+                            const double beta_next = beta_tab[t2 + 1 < n_iter2 ? t2 + 1 : t2];
+                            const double ut = fma(beta, uu - up, uu);
                             const double base = mode == 1 ? uu : ut;  // deconvolution.py:163 vs :88
                             up = uu;
-                            const double g = f_grad_row<NU>(cj, base, Mrow, lane0);
-                            uu = fmin(fmax(fma(g, inv_lw, ut), 0.0), 1.0);
+                            const double x = f_grad_row<NU>(ut + cj, base, Ms, lane0);
+                            uu = fmin(fmax(x, 0.0), 1.0);
+                            beta = beta_next;
                         }
                         if (ok) {
                             u[gi] = uu;
@@ -276,8 +323,11 @@ __global__ __launch_bounds__(512) void k_rowpass_fused(
                             u2_acc = fma(uu, uu, u2_acc);
                         }
                     }
+                    __builtin_amdgcn_s_setprio(0);
                 }
+                DMF_STAMP(3)  // phase B (or idle)
                 __syncthreads();  // ---- barrier Y
+                DMF_STAMP(4)  // wait at Y
             } else {
                 __syncthreads();  // X: the C team is finishing the last block
                 __syncthreads();  // Y
@@ -286,22 +336,26 @@ __global__ __launch_bounds__(512) void k_rowpass_fused(
         // share of ||u||^2 (red is free again: the last step's phase B is behind barrier Y)
         const double w2 = wave_sum(u2_acc);
         if (lane == 0) red[wave] = w2;
+        DMF_STAMP_FLUSH
     } else {
         // =========================== C team: phase C ==========================================
+        const int half = cidx / NW;  // rows [8 half, 8 half + 8) of every block
         double acc[NACC];
 #pragma unroll
         for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
         const int sC = wcol0 + lane;  // lane = sample column
 
         auto accum_rows = [&](int buf, int r_begin, int nvalid) {
-            const double* __restrict__ tileV = tile_of(buf);
-            const double* __restrict__ tileD = tileV + kTileDoubles;
+            const char* __restrict__ tile = tile_of(buf);
+            const double* __restrict__ tileV = reinterpret_cast<const double*>(tile);
+            const float* __restrict__ tileD = reinterpret_cast<const float*>(tile + kTileVBytes);
             const double* __restrict__ ub = ubuf + buf * 16 * NU;
             const double* __restrict__ rb = rtbuf + buf * 16 * NCTL;
-#pragma unroll 2
-            for (int r = r_begin; r < r_begin + 8; ++r) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = r_begin + rr;
                 if (r < nvalid) {
-                    const double d = tileD[r * kTileRowDoubles + lane];
+                    const double d = (double)tileD[r * kTileRowFloats + lane];
                     const double v = tileV[r * kTileRowDoubles + lane];
                     double uj[NU], t[NU];
 #pragma unroll
@@ -327,23 +381,29 @@ __global__ __launch_bounds__(512) void k_rowpass_fused(
             }
         };
 
+        DMF_STAMP_DECL
         for (int s = 0; s <= nk; ++s) {
             int nvalid = 0, buf = 0;
             if (s >= 1) {
                 const int64_t row0 = (blockIdx.x + (int64_t)(s - 1) * gridDim.x) * 16;
                 nvalid = N - row0 < 16 ? (int)(N - row0) : 16;
                 buf = (s - 1) & 1;
-                accum_rows(buf, 0, nvalid);
+                accum_rows(buf, 8 * half, nvalid);
             }
+            DMF_STAMP(0)  // first 4 rows
             __syncthreads();  // ---- barrier X
-            if (s >= 1) accum_rows(buf, 8, nvalid);
+            DMF_STAMP(2)  // wait at X
+            if (s >= 1) accum_rows(buf, 8 * half + 4, nvalid);
+            DMF_STAMP(1)  // last 4 rows
             __syncthreads();  // ---- barrier Y
+            DMF_STAMP(4)  // wait at Y
         }
+        DMF_STAMP_FLUSH
 
-        // ---- slab of this workgroup (job order of the solver's table)
+        // ---- slab of this wave's half of the workgroup (job order of the solver's table)
         if (sC < S) {
             const int n_jobs = n_c * NU + NP + NU;
-            double* __restrict__ out = slab + (int64_t)blockIdx.x * n_jobs * S + sC;
+            double* __restrict__ out = slab + ((int64_t)blockIdx.x * 2 + half) * n_jobs * S + sC;
 #pragma unroll
             for (int a = 0; a < NACC; ++a) {
                 int job = -1;
@@ -385,11 +445,12 @@ __global__ __launch_bounds__(256) void k_finish_u_norm(const double* __restrict_
     }
 }
 
-static size_t fused_lds_bytes(int S, int nct, int n_u, int n_iter2) {
+size_t fused_lds_bytes(int S, int nct, int n_u, int n_iter2) {
     const int NW = (S + 63) / 64;
     const int nv = n_u + n_u * (n_u + 1) / 2;
-    return ((size_t)((n_iter2 + 1) & ~1) + 2 * 16 * n_u + 2 * 16 * (nct > 0 ? nct : 1) + (size_t)NW * nv * 16 +
-            (size_t)2 * NW * 2 * kTileDoubles) * sizeof(double);
+    const size_t doubles = (size_t)((n_iter2 + 1) & ~1) + 2 * 16 * n_u + 2 * 16 * (nct > 0 ? nct : 1) +
+                           (size_t)NW * nv * 16 + (size_t)(nct + n_u + 1) * (NW * 64 + 2);
+    return doubles * sizeof(double) + (size_t)2 * NW * kTileBytes;
 }
 
 bool rowpass_fused_supported(int S, int n_c, int n_u) {
@@ -407,7 +468,7 @@ int rowpass_fused_grid(int64_t N, int S) {
 }
 
 int64_t rowpass_fused_slab_doubles(int64_t N, int S, int n_c, int n_u) {
-    return (int64_t)rowpass_fused_grid(N, S) * (n_c * n_u + n_u * (n_u + 1) / 2 + n_u) * S;
+    return (int64_t)2 * rowpass_fused_grid(N, S) * (n_c * n_u + n_u * (n_u + 1) / 2 + n_u) * S;
 }
 
 template <int NKC, int NU>
@@ -427,9 +488,13 @@ static hipError_t launch_fused_t(const double* V, const double* D, const double*
             if (e != hipSuccess) return e;
         }
         const int grid = rowpass_fused_grid(N, S);
-        *grid_out = grid;
-        hipLaunchKernelGGL((k_rowpass_fused<NKC, NU>), dim3(grid), dim3(2 * NW * 64), lds, st, V, D, Rtp, alpha, u,
-                           u_prev, state, N, S, n_c, n_iter2, mode, slab, u2_partials);
+        *grid_out = 2 * grid;  // slab rows: two C-team halves per workgroup
+        hipLaunchKernelGGL((k_rowpass_fused<NKC, NU>), dim3(grid), dim3(DMF_WAVES_PER_WG(NW) * 64), lds, st, V, D, Rtp, alpha, u,
+                           u_prev, state, N, S, n_c, n_iter2, mode, slab, u2_partials
+#ifdef DMF_STAMPS
+                           , (unsigned long long*)nullptr
+#endif
+                           );
         hipLaunchKernelGGL(k_finish_u_norm, dim3(1), dim3(256), 0, st, u2_partials, grid, state);
         return hipGetLastError();
     }

@@ -21,36 +21,38 @@ hipError_t launch_convert_counts(const long long* src, double* dst, int64_t n, h
     return hipGetLastError();
 }
 
-template <bool SQUARE_SUM>
+// MODE 0: max(x)   MODE 1: sum(x^2)   MODE 2: max |x - (double)(float)x|  (is x exact in f32?)
+template <int MODE>
 __global__ __launch_bounds__(256) void k_reduce_partial(const double* __restrict__ x, int64_t n,
                                                         double* __restrict__ partial,
                                                         const int* __restrict__ done_flag) {
     __shared__ double red[4];
     if (done_flag != nullptr && *done_flag) return;
-    double acc = SQUARE_SUM ? 0.0 : -INFINITY;
+    double acc = MODE == 1 ? 0.0 : -INFINITY;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (; i < n; i += stride) {
         const double v = x[i];
-        if (SQUARE_SUM) acc = fma(v, v, acc);
-        else acc = fmax(acc, v);
+        if (MODE == 1) acc = fma(v, v, acc);
+        else if (MODE == 0) acc = fmax(acc, v);
+        else acc = fmax(acc, fabs(v - (double)(float)v));
     }
-    const double tot = SQUARE_SUM ? block_sum<256>(acc, red) : block_max<256>(acc, red);
+    const double tot = MODE == 1 ? block_sum<256>(acc, red) : block_max<256>(acc, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
-template <bool SQUARE_SUM>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_reduce_final(const double* __restrict__ partial, int n,
                                                       double* __restrict__ out,
                                                       const int* __restrict__ done_flag) {
     __shared__ double red[4];
     if (done_flag != nullptr && *done_flag) return;
-    double acc = SQUARE_SUM ? 0.0 : -INFINITY;
+    double acc = MODE == 1 ? 0.0 : -INFINITY;
     for (int i = threadIdx.x; i < n; i += 256) {
-        if (SQUARE_SUM) acc += partial[i];
+        if (MODE == 1) acc += partial[i];
         else acc = fmax(acc, partial[i]);
     }
-    const double tot = SQUARE_SUM ? block_sum<256>(acc, red) : block_max<256>(acc, red);
+    const double tot = MODE == 1 ? block_sum<256>(acc, red) : block_max<256>(acc, red);
     if (threadIdx.x == 0) *out = tot;
 }
 
@@ -63,16 +65,23 @@ static inline int reduce_blocks(int64_t n) {
 
 hipError_t launch_max_f64(const double* x, int64_t n, double* scratch, double* out, hipStream_t st) {
     const int nb = reduce_blocks(n);
-    hipLaunchKernelGGL(k_reduce_partial<false>, dim3(nb), dim3(256), 0, st, x, n, scratch, (const int*)nullptr);
-    hipLaunchKernelGGL(k_reduce_final<false>, dim3(1), dim3(256), 0, st, scratch, nb, out, (const int*)nullptr);
+    hipLaunchKernelGGL(k_reduce_partial<0>, dim3(nb), dim3(256), 0, st, x, n, scratch, (const int*)nullptr);
+    hipLaunchKernelGGL(k_reduce_final<0>, dim3(1), dim3(256), 0, st, scratch, nb, out, (const int*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_residual_max(const double* x, int64_t n, double* scratch, double* out, hipStream_t st) {
+    const int nb = reduce_blocks(n);
+    hipLaunchKernelGGL(k_reduce_partial<2>, dim3(nb), dim3(256), 0, st, x, n, scratch, (const int*)nullptr);
+    hipLaunchKernelGGL(k_reduce_final<0>, dim3(1), dim3(256), 0, st, scratch, nb, out, (const int*)nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_sumsq_f64(const double* x, int64_t n, double* scratch, double* out,
                             const int* done_flag, hipStream_t st) {
     const int nb = reduce_blocks(n);
-    hipLaunchKernelGGL(k_reduce_partial<true>, dim3(nb), dim3(256), 0, st, x, n, scratch, done_flag);
-    hipLaunchKernelGGL(k_reduce_final<true>, dim3(1), dim3(256), 0, st, scratch, nb, out, done_flag);
+    hipLaunchKernelGGL(k_reduce_partial<1>, dim3(nb), dim3(256), 0, st, x, n, scratch, done_flag);
+    hipLaunchKernelGGL(k_reduce_final<1>, dim3(1), dim3(256), 0, st, scratch, nb, out, done_flag);
     return hipGetLastError();
 }
 
@@ -171,7 +180,7 @@ hipError_t launch_cost(const double* V, const double* D, const double* Rt, const
     const int in_lds = lds <= 48 * 1024;
     hipLaunchKernelGGL(k_cost, dim3(nb), dim3(256), in_lds ? lds : 0, st, V, D, Rt, u, alpha, N, S,
                        n_c, n_u, in_lds, scratch);
-    hipLaunchKernelGGL(k_reduce_final<true>, dim3(1), dim3(256), 0, st, scratch, nb, out,
+    hipLaunchKernelGGL(k_reduce_final<1>, dim3(1), dim3(256), 0, st, scratch, nb, out,
                        (const int*)nullptr);
     return hipGetLastError();
 }
@@ -265,18 +274,39 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
                                                      const int* __restrict__ dst_row,
                                                      double* __restrict__ gb,
                                                      const int* __restrict__ done_flag) {
+    // block = 32 sample columns x 8 slab lanes; lane yl sums slabs yl, yl + 8, ... (4 loads in flight),
+    // then the 8 partial sums are added in fixed order: deterministic.
+    __shared__ double part[8][32];
     if (done_flag != nullptr && *done_flag) return;
-    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int c = threadIdx.x & 31, yl = threadIdx.x >> 5;
+    const int s = blockIdx.x * 32 + c;
     const int a = blockIdx.y;
-    if (s >= S) return;
-    double tot = 0.0;
-    for (int y = 0; y < ny; ++y) tot += slab[((int64_t)y * n_jobs + a) * S + s];
-    gb[(int64_t)dst_row[a] * S + s] = tot;
+    const bool ok = s < S;
+    const int sc = ok ? s : S - 1;
+    const double* __restrict__ src = slab + (int64_t)a * S + sc;
+    const int64_t ystride = (int64_t)n_jobs * S;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    int y = yl;
+    for (; y + 24 < ny; y += 32) {
+        t0 += src[(int64_t)y * ystride];
+        t1 += src[(int64_t)(y + 8) * ystride];
+        t2 += src[(int64_t)(y + 16) * ystride];
+        t3 += src[(int64_t)(y + 24) * ystride];
+    }
+    for (; y < ny; y += 8) t0 += src[(int64_t)y * ystride];
+    part[yl][c] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (yl == 0 && ok) {
+        double tot = part[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) tot += part[k][c];
+        gb[(int64_t)dst_row[a] * S + s] = tot;
+    }
 }
 
 hipError_t launch_gram_reduce(const double* slab, int ny, int n_jobs, int S, const int* dst_row,
                               double* gb, const int* done_flag, hipStream_t st) {
-    hipLaunchKernelGGL(k_gram_reduce, dim3((S + 255) / 256, n_jobs), dim3(256), 0, st, slab, ny, n_jobs, S,
+    hipLaunchKernelGGL(k_gram_reduce, dim3((S + 31) / 32, n_jobs), dim3(256), 0, st, slab, ny, n_jobs, S,
                        dst_row, gb, done_flag);
     return hipGetLastError();
 }
@@ -291,7 +321,7 @@ hipError_t launch_gram(const double* V, const double* D, const double* Rt, const
     if ((int64_t)ny * jobs.count * S > slab_doubles) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_gram, dim3(nsx, ny, nz), dim3(256), 0, st, V, D, Rt, u, N, S, n_c, n_u,
                        jobs.k_idx, jobs.l_idx, jobs.count, rpc, slab, done_flag);
-    hipLaunchKernelGGL(k_gram_reduce, dim3((S + 255) / 256, jobs.count), dim3(256), 0, st, slab, ny,
+    hipLaunchKernelGGL(k_gram_reduce, dim3((S + 31) / 32, jobs.count), dim3(256), 0, st, slab, ny,
                        jobs.count, S, jobs.dst_row, gb, done_flag);
     return hipGetLastError();
 }
