@@ -1,0 +1,99 @@
+"""Bootstrap confidence intervals: host-side mirror of demethify/bootstrap.py.
+
+Replicate i resamples the CpG rows with replacement (``sklearn.utils.resample(..., random_state=seed_i)``
+upstream, i.e. ``RandomState(seed_i).randint(0, N, N)`` applied to meth_f, counts and ref alike), runs a
+full solve on the resampled problem and contributes one column per sample / unknown to the percentile
+bounds.  The full data set is uploaded once; each replicate is a row gather on the device.  With
+torch.distributed initialised, replicate i runs on rank i mod world and the per-replicate factors are
+gathered.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+
+from . import _lib as L
+from . import shard
+from .deconvolution import init_BSSMF_md, solve_problem
+from .device import Problem, get_context
+from .init_func import wls_intercept
+
+__all__ = ["bt_ci", "bootstrap_seed_sequence", "bootstrap_row_indices"]
+
+
+def bootstrap_seed_sequence(seed, n_bootstrap):
+    """bootstrap.py:27: ``seed = seed + i`` inside the loop is cumulative (seed_0 + i (i + 1) / 2).
+    A list-valued seed (CLI ``--seed s``) fails here exactly as upstream does (TypeError)."""
+    out = []
+    for i in range(n_bootstrap):
+        seed = seed + i if seed is not None else None
+        out.append(seed)
+    return out
+
+
+def bootstrap_row_indices(seed, n_rows):
+    """Row indices sklearn's ``resample`` draws for ``random_state=seed`` (bootstrap.py:28)."""
+    return np.random.RandomState(seed).randint(0, n_rows, size=(n_rows,))
+
+
+def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, n_iter1, n_iter2, tol, header,
+          outdir, samples, purity, seed):
+    """bootstrap.py:10-93 -> [proportions CI DataFrame, (profile CI DataFrame)]; writes the two CSVs."""
+    if purity:
+        raise NotImplementedError("the purity-constrained solver (deconvolution.py:228-337) is not part of this build")
+    supervised = n_u == 0
+    a = 1 - confidence_level / 100
+    lower_percentile = 100 * (a / 2)
+    upper_percentile = 100 * (1 - (a / 2))
+    n_rows, n_samples = meth_f.shape
+    n_ct = ref.shape[1]
+
+    rank, world, _ = shard.dist_state()
+    seeds = bootstrap_seed_sequence(seed, n_bootstrap)
+    local = []
+    if supervised:
+        for i in shard.my_items(n_bootstrap, rank, world):
+            idx = bootstrap_row_indices(seeds[i], n_rows)
+            mf, ct, rf = meth_f[idx], counts[idx], ref[idx]
+            props = np.concatenate([wls_intercept(ct[:, k:k + 1] * mf[:, k:k + 1], ct[:, k:k + 1], rf)
+                                    for k in range(n_samples)], axis=1)
+            local.append((i, (None, props)))
+    else:
+        with Problem(get_context(), meth_f, counts, ref) as full:
+            for i in shard.my_items(n_bootstrap, rank, world):
+                idx = bootstrap_row_indices(seeds[i], n_rows)
+                needs_data = init_option == "uniform"
+                mf = meth_f[idx] if needs_data else np.broadcast_to(meth_f[:1], meth_f.shape)
+                ct = counts[idx] if needs_data else np.broadcast_to(counts[:1], counts.shape)
+                rf = ref[idx] if needs_data else np.broadcast_to(ref[:1], ref.shape)
+                u0, _, a0 = init_BSSMF_md(init_option, mf, ct, rf, n_u, rb_alg=wls_intercept, seed=seeds[i])
+                with full.gather(idx) as resampled:
+                    u, alpha = solve_problem(resampled, u0, a0, L.DMF_MODE_PARTIAL, n_iter1, n_iter2, tol)
+                local.append((i, (u, alpha)))
+    merged = shard.gather_objects(local)
+    props_stack = np.stack([pa for _, (_, pa) in merged])  # (B, K, S)
+
+    results = []
+    lower_p = np.percentile(props_stack, lower_percentile, axis=0)
+    upper_p = np.percentile(props_stack, upper_percentile, axis=0)
+    unknown_header = [] if supervised else ["unknown_cell_" + str(i + 1) for i in range(n_u)]
+    cell_types = header + unknown_header
+    table = {f"Sample_{i + 1}": [(lower_p[k, i], upper_p[k, i]) for k in range(n_ct + n_u)]
+             for i in range(n_samples)}
+    proportions_df = pd.DataFrame(table, index=cell_types)
+    proportions_df.columns = samples
+    proportions_df.index.name = "Cell Type"
+    if rank == 0:
+        proportions_df.to_csv(outdir + "/confidence_interval_celltypes_proportions.csv", index=True)
+    results.append(proportions_df)
+
+    if not supervised:
+        u_stack = np.stack([pu for _, (pu, _) in merged])  # (B, N, n_u), by resampled position as upstream
+        lower_u = np.percentile(u_stack, lower_percentile, axis=0)
+        upper_u = np.percentile(u_stack, upper_percentile, axis=0)
+        ref_estimate_df = pd.DataFrame({unknown_header[k]: [(lower_u[j, k], upper_u[j, k]) for j in range(n_rows)]
+                                        for k in range(n_u)})
+        if rank == 0:
+            ref_estimate_df.to_csv(outdir + "/confidence_interval_methylation_estimate.csv", index=False)
+        results.append(ref_estimate_df)
+    return results

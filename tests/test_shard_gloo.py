@@ -1,0 +1,94 @@
+"""Multi-process (gloo, world_size 2) tests of the sharding layer on CPU: the restart pick, the cost
+all-reduce and the object gather must give every rank the same answer as a serial run.  The solver
+is injected (CPU oracle on a toy problem) because the product solver needs a GPU."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _toy():
+    from oracle import solver as osol
+
+    V, D, Rt = osol.synthetic_problem(200, 6, 3, 1, seed=4, depth=15)
+    return V, D, Rt
+
+
+def _solve_restart(k):
+    from demethify_amd.shard import restart_seed
+    from oracle import drivers as odrv
+    from oracle import solver as osol
+
+    V, D, Rt = _toy()
+    u, R, alpha = odrv.run_one(V, D, Rt, 1, "uniform_", restart_seed(1, k), 30, 5, 1e-3,
+                               project=osol.simplex_project_columns_fast)
+    return u, alpha, float(osol.weighted_cost(V, R, alpha, D))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from demethify_amd import shard
+
+    assert shard.dist_state()[:2] == (rank, world)
+    # 1. cost vector all-reduce + first-minimum pick
+    vec = shard.allreduce_min_vector({k: float((k * 7) % 5) for k in shard.my_items(9)}, 9)
+    assert np.array_equal(vec, np.array([(k * 7) % 5 for k in range(9)], dtype=float))
+    assert shard.argmin_first(vec) == 0
+    # 2. sharded restarts == serial pick, identical on every rank
+    u, alpha, best_k, costs = shard.sharded_restarts(5, _solve_restart, ((200, 1), (4, 6)))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), u=u, alpha=alpha, best_k=best_k, costs=costs)
+    # 3. object gather keeps item order
+    merged = shard.gather_objects([(k, k * k) for k in shard.my_items(7)])
+    assert merged == [(k, k * k) for k in range(7)]
+    # 4. broadcast from a non-zero owner
+    payload = (np.full((3, 2), 5.0),) if rank == 1 else (np.empty((3, 2)),)
+    (got,) = shard.broadcast_arrays(payload, 1)
+    assert np.array_equal(got, np.full((3, 2), 5.0))
+    dist.destroy_process_group()
+
+
+def test_sharded_restarts_match_serial(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    serial = [_solve_restart(k) for k in range(5)]
+    costs = np.array([c for _, _, c in serial])
+    best = int(np.argmin(costs))
+    for rank in range(world):
+        z = np.load(tmp_path / f"rank{rank}.npz")
+        assert int(z["best_k"]) == best
+        assert np.array_equal(z["costs"], costs)
+        assert np.array_equal(z["u"], serial[best][0]) and np.array_equal(z["alpha"], serial[best][1])
+
+
+def test_restart_seed_convention():
+    from demethify_amd.shard import restart_seed
+
+    assert restart_seed(1, 0) == 1 and restart_seed(1, 3) == 4
+    assert restart_seed([5], 0) == [5] and restart_seed([5], 2) == [7]
+    assert restart_seed(None, 4) is None
+
+
+def test_single_process_fallbacks():
+    from demethify_amd import shard
+
+    assert shard.dist_state() == (0, 1, None)
+    assert shard.my_items(4) == [0, 1, 2, 3]
+    assert np.array_equal(shard.allreduce_min_vector({1: 2.0}, 3), np.array([np.inf, 2.0, np.inf]))
+    assert shard.gather_objects([(1, "b"), (0, "a")]) == [(0, "a"), (1, "b")]
