@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=40_000)
     ap.add_argument("--kernels", type=int, default=0, choices=[0, 1, 2, 3],
                     help="kernel selection level (dmf_context_set_generic): 0 = fused row pass (default)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo + --share-gpu rehearses the N > 1 path on a one-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -112,11 +115,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     from demethify_amd import _lib as L
     from demethify_amd.device import Context, Problem, Solver
@@ -148,14 +156,14 @@ def main():
     iters, _ = solver.step(args.steps, 20, 0.0)
     ctx.synchronize()
     if world > 1:
-        cost = solver.get_cost()
+        cost, _ = solver.get_cost()
         best_rank, best_cost = pick_min_cost(cost, rank, world, dev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert iters == args.warmup + args.steps, (iters, args.warmup, args.steps)
@@ -167,18 +175,25 @@ def main():
         b_alg = algorithmic_bytes(N, S, n_c, n_u)
         fam_ms = {k: (v[0] / max(v[1], 1), v[1]) for k, v in fam.items()}
         # dominant kernel family of the outer iteration and its algorithmic traffic per launch
+        # With the fused row pass (--kernels 0) ONE launch of the "rowpass" family does the whole V / D
+        # stream of an outer iteration: B_alg of SURVEY.md 8(d).  The unfused pair (--kernels 3) reads V
+        # and D once per kernel.
         per_launch_bytes = {
             "rowpass": N * S * 16 + N * 8 * (n_c + 3 * n_u),   # V, D, R_trunc, u, u_ in; u out
-            "gram": N * S * 16 + N * 8 * (n_c + n_u),          # V, D, R_trunc, u in
+            "gram": N * S * 16 + N * 8 * (n_c + n_u),          # V, D, R_trunc, u in (unfused levels only)
         }
         dom = max(("rowpass", "gram"), key=lambda k: fam[k][0])
+        kernel_names = {0: {"rowpass": "k_rowpass_fused", "gram": "k_gram_reduce"},
+                        3: {"rowpass": "k_u_phase_mfma", "gram": "k_gram_u"},
+                        1: {"rowpass": "k_u_phase_gram", "gram": "k_gram"},
+                        2: {"rowpass": "k_u_step_direct", "gram": "k_gram"}}[args.kernels]
         dom_ms = fam_ms[dom][0]
         achieved = per_launch_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get(args.workload, {}).get(dom)
+                traffic = json.loads(tfile.read_text()).get(args.workload, {}).get(kernel_names[dom], {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         ms_per_step = elapsed / args.steps * 1e3
@@ -200,7 +215,7 @@ def main():
                        "inner_iters": 20, "unit_of_work": "one outer iteration = 20 u + 20 alpha inner updates + cost",
                        "parallelism": f"restart-sharded x{world}" if world > 1 else "single solve"},
             "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": kernel_names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": per_launch_bytes[dom],
                 "avg_launch_ms": dom_ms,

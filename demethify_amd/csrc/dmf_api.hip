@@ -301,9 +301,10 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
                                               (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, s->slab,
                                               s->u2_partials, &grid, ctx->stream));
         }
+        HIP_TRY(dmf::launch_finish_u_norm(s->u2_partials, grid, s->state, ctx->stream));
         {
             FamilyScope scope(ctx, DMF_KERNEL_GRAM);
-            HIP_TRY(dmf::launch_gram_reduce(s->slab, grid, s->n_jobs, (int)p->S, s->job_dst, s->gb,
+            HIP_TRY(dmf::launch_gram_reduce(s->slab, 2 * grid, s->n_jobs, (int)p->S, s->job_dst, s->gb,
                                             &s->state->done, ctx->stream));
         }
         DMF_TRY(enqueue_alpha_phase(s, n_iter2));

@@ -89,7 +89,8 @@ hipError_t launch_u_phase_mfma(const double* V, const double* D, const double* R
                                double* u, double* u_prev, const SolverState* state, int64_t N, int S,
                                int n_c, int n_u, int n_iter2, int mode, hipStream_t st);
 // fused row pass: u phase + u-dependent Gram slab + ||u||^2 / l_h in one read of V and D
-// (S % 4 == 0, S <= 512, n_c <= 16, n_u <= 8, accumulators <= 80); slab rows = workgroups
+// (S % 4 == 0, S <= 256, n_c <= 16, n_u <= 8, accumulators <= 80, counts exact in f32);
+// grid_out = workgroups launched; the slab holds 2 rows per workgroup
 bool rowpass_fused_supported(int S, int n_c, int n_u);
 int rowpass_fused_grid(int64_t N, int S);
 int64_t rowpass_fused_slab_doubles(int64_t N, int S, int n_c, int n_u);
@@ -97,6 +98,8 @@ hipError_t launch_rowpass_fused(const double* V, const double* D, const double* 
                                 double* u, double* u_prev, SolverState* state, int64_t N, int S, int n_c,
                                 int n_u, int n_iter2, int mode, double* slab, double* u2_partials,
                                 int* grid_out, hipStream_t st);
+// sum of the fused kernel's per-workgroup ||u||^2 shares -> state->u_norm2 and l_h (deconvolution.py:212)
+hipError_t launch_finish_u_norm(const double* u2_partials, int n, SolverState* state, hipStream_t st);
 // u phase, schedule-faithful fallback: ONE inner iteration (index t) per launch
 hipError_t launch_u_step_direct(const double* V, const double* D, const double* Rt,
                                 const double* alpha, const double* u_cur, const double* u_prev,

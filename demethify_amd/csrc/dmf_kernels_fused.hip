@@ -453,6 +453,11 @@ size_t fused_lds_bytes(int S, int nct, int n_u, int n_iter2) {
     return doubles * sizeof(double) + (size_t)2 * NW * kTileBytes;
 }
 
+hipError_t launch_finish_u_norm(const double* u2_partials, int n, SolverState* state, hipStream_t st) {
+    hipLaunchKernelGGL(k_finish_u_norm, dim3(1), dim3(256), 0, st, u2_partials, n, state);
+    return hipGetLastError();
+}
+
 bool rowpass_fused_supported(int S, int n_c, int n_u) {
     if ((S & 3) != 0 || S > 256 || n_c > 16 || n_u < 1 || n_u > 8) return false;
     const int nct = (n_c + 3) / 4 * 4;
@@ -488,14 +493,13 @@ static hipError_t launch_fused_t(const double* V, const double* D, const double*
             if (e != hipSuccess) return e;
         }
         const int grid = rowpass_fused_grid(N, S);
-        *grid_out = 2 * grid;  // slab rows: two C-team halves per workgroup
+        *grid_out = grid;
         hipLaunchKernelGGL((k_rowpass_fused<NKC, NU>), dim3(grid), dim3(DMF_WAVES_PER_WG(NW) * 64), lds, st, V, D, Rtp, alpha, u,
                            u_prev, state, N, S, n_c, n_iter2, mode, slab, u2_partials
 #ifdef DMF_STAMPS
                            , (unsigned long long*)nullptr
 #endif
                            );
-        hipLaunchKernelGGL(k_finish_u_norm, dim3(1), dim3(256), 0, st, u2_partials, grid, state);
         return hipGetLastError();
     }
 }
