@@ -68,15 +68,24 @@ __device__ __forceinline__ double f_group_bcast(double x, int lane0) {
     else return __shfl(x, lane0 + L, 64);
 }
 
-// acc - sum_l base_l * Ms[l] over the NU lanes of a row group
-template <int NU, int L = 0>
-__device__ __forceinline__ double f_grad_row(double acc, double base, const double (&Ms)[NU], int lane0) {
-    if constexpr (L < NU) {
-        acc = fma(-f_group_bcast<NU, L>(base, lane0), Ms[L], acc);
-        return f_grad_row<NU, L + 1>(acc, base, Ms, lane0);
+// sum_l base_l * Ms[l] over the NU lanes of a row group, as a balanced tree: phase B is one dependent
+// chain on the workgroup's critical path, so its depth (not its instruction count) is what costs
+template <int NU, int L0, int L1>
+__device__ __forceinline__ double f_dot_tree(double base, const double (&Ms)[NU], int lane0) {
+    if constexpr (L1 - L0 == 1) {
+        return f_group_bcast<NU, L0>(base, lane0) * Ms[L0];
     } else {
-        return acc;
+        constexpr int MID = (L0 + L1) / 2;
+        return f_dot_tree<NU, L0, MID>(base, Ms, lane0) + f_dot_tree<NU, MID, L1>(base, Ms, lane0);
     }
+}
+
+// clip(a - b, 0, 1) in one instruction: the VOP3 clamp modifier clamps an FP result to [0, 1]
+// (np.clip(x, 0, 1) of deconvolution.py:88; a NaN would come out as 0 instead of NaN)
+__device__ __forceinline__ double f_sub_clamp01(double a, double b) {
+    double r;
+    asm("v_add_f64 %0, %1, -%2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // Team layout: a workgroup has 3 NW waves (NW = ceil(S / 64) column groups of 64 samples).
@@ -118,13 +127,14 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
     const int wcol0 = cg * 64;
 
     // LDS carve-up (doubles unless noted):
-    //   beta[n_iter2 (even)] | ubuf[2][16][NU] | rtbuf[2][16][NCT] | red[NW][NV][16] |
+    //   beta[n_iter2 (even)] | ubuf[2][16][NU] | upbuf[2][16][NU] | rtbuf[2][16][NCT] | red[NW][NV][16] |
     //   alds[(NCT + NU + 1) rows][AS]: -alpha_known (zero-padded to NCT rows), alpha_unk, one zero row |
     //   tiles[2 buffers][NW groups]{ V f64 [16][66], D f32 [16][68] }
     const int AS = NW * 64 + 2;  // alpha row stride in LDS
     double* __restrict__ beta_tab = lds_dyn;
     double* __restrict__ ubuf = beta_tab + ((n_iter2 + 1) & ~1);
-    double* __restrict__ rtbuf = ubuf + 2 * 16 * NU;
+    double* __restrict__ upbuf = ubuf + 2 * 16 * NU;  // u_ rows, stored to HBM by a C wave
+    double* __restrict__ rtbuf = upbuf + 2 * 16 * NU;
     double* __restrict__ red = rtbuf + 2 * 16 * NCTL;
     double* __restrict__ alds = red + NW * NV * 16;
     char* __restrict__ tiles = reinterpret_cast<char*>(alds + (size_t)(NCT + NU + 1) * AS);
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                     *reinterpret_cast<v2f*>(tileD + (2 * i + ld_row) * kTileRowFloats + ld_col) =
                         v2f{(float)pd[i].x, (float)pd[i].y};
                 }
+                DMF_STAMP(5)  // tile store (waits for the prefetched loads)
                 double rtop[NKC > 0 ? NKC : 1];
 #pragma unroll
                 for (int kc = 0; kc < NKC; ++kc) {
@@ -251,14 +262,29 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                         e = __builtin_amdgcn_mfma_f64_16x16x4f64(alds[(kc * 4 + q) * AS + e_col + 16 * t], rtop[kc], e,
                                                                  0, 0, 0);
                     const v4d w = d * e;
+                    // operand rows: this lane's four samples are contiguous and 16-B aligned in alds
+                    const int col = k_col + 16 * t;
+                    const v2d a2lo = *reinterpret_cast<const v2d*>(alds + a2_row * AS + col);
+                    const v2d a2hi = *reinterpret_cast<const v2d*>(alds + a2_row * AS + col + 2);
+                    const double a2v[4] = {a2lo.x, a2lo.y, a2hi.x, a2hi.y};
+                    double pv4[NMT][4];
+#pragma unroll
+                    for (int mt = 0; mt < NMT; ++mt) {
+                        const v2d jlo = *reinterpret_cast<const v2d*>(alds + jp_row[mt] * AS + col);
+                        const v2d jhi = *reinterpret_cast<const v2d*>(alds + jp_row[mt] * AS + col + 2);
+                        const v2d llo = *reinterpret_cast<const v2d*>(alds + lp_row[mt] * AS + col);
+                        const v2d lhi = *reinterpret_cast<const v2d*>(alds + lp_row[mt] * AS + col + 2);
+                        pv4[mt][0] = jlo.x * llo.x;
+                        pv4[mt][1] = jlo.y * llo.y;
+                        pv4[mt][2] = jhi.x * lhi.x;
+                        pv4[mt][3] = jhi.y * lhi.y;
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int col = k_col + 16 * t + r;
-                        cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(alds[a2_row * AS + col], w[r], cacc, 0, 0, 0);
+                        cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2v[r], w[r], cacc, 0, 0, 0);
 #pragma unroll
                         for (int mt = 0; mt < NMT; ++mt)
-                            macc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-                                alds[jp_row[mt] * AS + col] * alds[lp_row[mt] * AS + col], d[r], macc[mt], 0, 0, 0);
+                            macc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(pv4[mt][r], d[r], macc[mt], 0, 0, 0);
                     }
                 }
                 double* __restrict__ mine = red + (size_t)wave * NV * 16;
@@ -284,6 +310,7 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                     __builtin_amdgcn_s_setprio(3);
                     const int lane0 = lane - j;
                     double* __restrict__ ub = ubuf + (s & 1) * 16 * NU;
+                    double* __restrict__ upb = upbuf + (s & 1) * 16 * NU;
                     for (int pass0 = 0; pass0 < 16; pass0 += RPW) {
                         const int rloc = pass0 + rl;
                         const bool ok = rl < RPW && rloc < nvalid;
@@ -312,14 +339,14 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                             const double ut = fma(beta, uu - up, uu);
                             const double base = mode == 1 ? uu : ut;  // deconvolution.py:163 vs :88
                             up = uu;
-                            const double x = f_grad_row<NU>(ut + cj, base, Ms, lane0);
-                            uu = fmin(fmax(x, 0.0), 1.0);
+                            uu = f_sub_clamp01(ut + cj, f_dot_tree<NU, 0, NU>(base, Ms, lane0));
                             beta = beta_next;
                         }
                         if (ok) {
-                            u[gi] = uu;
-                            u_prev[gi] = up;
+                            // to LDS only: a C wave stores the rows to HBM next step, so that no A wave ever
+                            // has a store in flight when its next tile write waits on vmcnt
                             ub[rloc * NU + j] = uu;
+                            upb[rloc * NU + j] = up;
                             u2_acc = fma(uu, uu, u2_acc);
                         }
                     }
@@ -354,30 +381,42 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int r = r_begin + rr;
-                if (r < nvalid) {
-                    const double d = (double)tileD[r * kTileRowFloats + lane];
-                    const double v = tileV[r * kTileRowDoubles + lane];
-                    double uj[NU], t[NU];
+                // rows past the end of the matrix hold a copy of row N-1: their weight is zeroed (no branch,
+                // so that the LDS reads of the four rows can all be in flight)
+                const double dm = r < nvalid ? 1.0 : 0.0;
+                const double d = dm * (double)tileD[r * kTileRowFloats + lane];
+                const double v = tileV[r * kTileRowDoubles + lane];
+                double uj[NU], t[NU];
+                if constexpr ((NU & 1) == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < NU; jj += 2) {  // 16-B broadcast reads
+                        const v2d two = *reinterpret_cast<const v2d*>(ub + r * NU + jj);
+                        uj[jj] = two.x;
+                        uj[jj + 1] = two.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < NU; ++jj) uj[jj] = ub[r * NU + jj];
+                }
+#pragma unroll
+                for (int jj = 0; jj < NU; ++jj) t[jj] = d * uj[jj];
+#pragma unroll
+                for (int k = 0; k < NCT; k += 2) {
+                    const v2d rk2 = *reinterpret_cast<const v2d*>(rb + r * NCTL + k);
 #pragma unroll
                     for (int jj = 0; jj < NU; ++jj) {
-                        uj[jj] = ub[r * NU + jj];
-                        t[jj] = d * uj[jj];
+                        acc[k * NU + jj] = fma(rk2.x, t[jj], acc[k * NU + jj]);
+                        acc[(k + 1) * NU + jj] = fma(rk2.y, t[jj], acc[(k + 1) * NU + jj]);
                     }
-#pragma unroll
-                    for (int k = 0; k < NCT; ++k) {
-                        const double rk = rb[r * NCTL + k];
-#pragma unroll
-                        for (int jj = 0; jj < NU; ++jj) acc[k * NU + jj] = fma(rk, t[jj], acc[k * NU + jj]);
-                    }
-#pragma unroll
-                    for (int l = 0; l < NU; ++l)
-#pragma unroll
-                        for (int jj = 0; jj <= l; ++jj)
-                            acc[NCT * NU + tri(jj, l)] = fma(t[jj], uj[l], acc[NCT * NU + tri(jj, l)]);
-#pragma unroll
-                    for (int jj = 0; jj < NU; ++jj)
-                        acc[NCT * NU + NP + jj] = fma(t[jj], v, acc[NCT * NU + NP + jj]);
                 }
+#pragma unroll
+                for (int l = 0; l < NU; ++l)
+#pragma unroll
+                    for (int jj = 0; jj <= l; ++jj)
+                        acc[NCT * NU + tri(jj, l)] = fma(t[jj], uj[l], acc[NCT * NU + tri(jj, l)]);
+#pragma unroll
+                for (int jj = 0; jj < NU; ++jj)
+                    acc[NCT * NU + NP + jj] = fma(t[jj], v, acc[NCT * NU + NP + jj]);
             }
         };
 
@@ -388,6 +427,12 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                 const int64_t row0 = (blockIdx.x + (int64_t)(s - 1) * gridDim.x) * 16;
                 nvalid = N - row0 < 16 ? (int)(N - row0) : 16;
                 buf = (s - 1) & 1;
+                if (cidx == 0) {  // the block's rows are contiguous in u: coalesced stores
+                    for (int e = lane; e < nvalid * NU; e += 64) {
+                        u[row0 * NU + e] = ubuf[buf * 16 * NU + e];
+                        u_prev[row0 * NU + e] = upbuf[buf * 16 * NU + e];
+                    }
+                }
                 accum_rows(buf, 8 * half, nvalid);
             }
             DMF_STAMP(0)  // first 4 rows
@@ -448,7 +493,7 @@ __global__ __launch_bounds__(256) void k_finish_u_norm(const double* __restrict_
 size_t fused_lds_bytes(int S, int nct, int n_u, int n_iter2) {
     const int NW = (S + 63) / 64;
     const int nv = n_u + n_u * (n_u + 1) / 2;
-    const size_t doubles = (size_t)((n_iter2 + 1) & ~1) + 2 * 16 * n_u + 2 * 16 * (nct > 0 ? nct : 1) +
+    const size_t doubles = (size_t)((n_iter2 + 1) & ~1) + 4 * 16 * n_u + 2 * 16 * (nct > 0 ? nct : 1) +
                            (size_t)NW * nv * 16 + (size_t)(nct + n_u + 1) * (NW * 64 + 2);
     return doubles * sizeof(double) + (size_t)2 * NW * kTileBytes;
 }

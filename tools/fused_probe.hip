@@ -41,7 +41,8 @@ int main(int argc, char** argv) {
             const bool is_a = w < NW; if ((team == 0) != is_a) continue;
             for (int i = 0; i < 8; ++i) sum[i] += (double)hs[((size_t)b * 16 + w) * 8 + i]; ++cnt;
         }
-        double tot = 0; for (int i = 0; i < 5; ++i) tot += sum[i];
+        double tot = 0; for (int i = 0; i < 8; ++i) tot += sum[i];
+        if (team == 0) printf("   %-26s %6.1f %%  (%.0f cycles per block-step)\n", "tile store (vmcnt waits)", 100 * sum[5] / tot, sum[5] / cnt / ((N / 16.0) / grid));
         printf("%s team: mean cycles per wave %.0f over the kernel\n", team == 0 ? "A" : "C", tot / cnt);
         for (int i = 0; i < 5; ++i) printf("   %-26s %6.1f %%  (%.0f cycles per block-step)\n", team == 0 ? an[i] : cn[i], 100 * sum[i] / tot, sum[i] / cnt / ((N / 16.0) / grid));
     }
