@@ -285,6 +285,7 @@ int enqueue_alpha_phase(dmf_solver* s, int n_iter2) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
     FamilyScope scope(ctx, DMF_KERNEL_ALPHA);
+    dmf::set_alpha_thread_per_sample(ctx->generic_level == 1 || ctx->generic_level == 2);
     HIP_TRY(dmf::launch_alpha_phase(s->gb, s->alpha, s->alpha_prev, s->state, (int)p->S, (int)p->n_c,
                                     (int)s->n_u, n_iter2, s->partials, ctx->stream));
     return DMF_OK;
@@ -613,7 +614,7 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     if (e == hipSuccess) e = hipMalloc((void**)&s->alpha_prev, an);
     if (e == hipSuccess) e = hipMalloc((void**)&s->gb, gbn);
     if (e == hipSuccess) e = hipMalloc((void**)&s->slab, (size_t)s->slab_doubles * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->partials, (size_t)2 * nb_alpha * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->partials, (size_t)2 * (nb_alpha + S) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&s->u2_partials, 1024 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&s->state, sizeof(SolverState));
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_state, sizeof(SolverState));

@@ -111,6 +111,8 @@ bool u_step_direct_supported(int S, int n_c, int n_u);
 hipError_t launch_alpha_phase(const double* gb, double* alpha, double* alpha_prev,
                               SolverState* state, int S, int n_c, int n_u, int n_iter2,
                               double* partials, hipStream_t st);
+// partials must hold 2 * max(ceil(S / 64), ceil(S * 32 / 64)) doubles (lane-parallel kernel: G lanes per sample)
+void set_alpha_thread_per_sample(bool on);
 hipError_t launch_set_lh(SolverState* state, hipStream_t st);
 hipError_t launch_project_simplex(const double* X, double* out, int K, int S, double z,
                                   hipStream_t st);
