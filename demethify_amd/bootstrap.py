@@ -14,7 +14,7 @@ import pandas as pd
 
 from . import _lib as L
 from . import shard
-from .deconvolution import init_BSSMF_md, solve_problem
+from .deconvolution import init_BSSMF_md, init_BSSMF_md_p, solve_problem
 from .device import Problem, get_context
 from .init_func import wls_intercept
 
@@ -39,8 +39,11 @@ def bootstrap_row_indices(seed, n_rows):
 def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, n_iter1, n_iter2, tol, header,
           outdir, samples, purity, seed):
     """bootstrap.py:10-93 -> [proportions CI DataFrame, (profile CI DataFrame)]; writes the two CSVs."""
+    purity_frac = None
     if purity:
-        raise NotImplementedError("the purity-constrained solver (deconvolution.py:228-337) is not part of this build")
+        # upstream quirk kept: bt_ci takes the raw percentages and uses p / 100 (bootstrap.py:18) while main()
+        # passes 1 - p / 100 to the point estimate (demethify.py:77)
+        purity_frac = np.array(purity) / 100.0
     supervised = n_u == 0
     a = 1 - confidence_level / 100
     lower_percentile = 100 * (a / 2)
@@ -66,9 +69,14 @@ def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, 
                 mf = meth_f[idx] if needs_data else np.broadcast_to(meth_f[:1], meth_f.shape)
                 ct = counts[idx] if needs_data else np.broadcast_to(counts[:1], counts.shape)
                 rf = ref[idx] if needs_data else np.broadcast_to(ref[:1], ref.shape)
-                u0, _, a0 = init_BSSMF_md(init_option, mf, ct, rf, n_u, rb_alg=wls_intercept, seed=seeds[i])
+                if purity_frac is not None:
+                    u0, _, a0 = init_BSSMF_md_p(init_option, mf, ct, rf, n_u, purity_frac, seed=seeds[i],
+                                                rb_alg=wls_intercept)
+                else:
+                    u0, _, a0 = init_BSSMF_md(init_option, mf, ct, rf, n_u, rb_alg=wls_intercept, seed=seeds[i])
                 with full.gather(idx) as resampled:
-                    u, alpha = solve_problem(resampled, u0, a0, L.DMF_MODE_PARTIAL, n_iter1, n_iter2, tol)
+                    u, alpha = solve_problem(resampled, u0, a0, L.DMF_MODE_PARTIAL, n_iter1, n_iter2, tol,
+                                             purity=purity_frac)
                 local.append((i, (u, alpha)))
     merged = shard.gather_objects(local)
     props_stack = np.stack([pa for _, (_, pa) in merged])  # (B, K, S)

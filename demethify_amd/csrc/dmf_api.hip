@@ -78,6 +78,7 @@ struct dmf_solver {
     int u_path = 0;         // 0 MFMA, 1 Gram-form VALU, 2 schedule-faithful direct steps
     bool use_gram_spec = false;
     bool use_fused = false;
+    double* purity = nullptr;  // S per-sample known-block masses: set => Frank-Wolfe alpha phase
     double* u2_partials = nullptr;
     double *u = nullptr, *u_prev = nullptr, *u_next = nullptr;
     double *alpha = nullptr, *alpha_prev = nullptr;
@@ -285,6 +286,11 @@ int enqueue_alpha_phase(dmf_solver* s, int n_iter2) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
     FamilyScope scope(ctx, DMF_KERNEL_ALPHA);
+    if (s->purity != nullptr) {
+        HIP_TRY(dmf::launch_alpha_frank_wolfe(s->gb, s->alpha, s->purity, s->state, (int)p->S, (int)p->n_c,
+                                              (int)s->n_u, n_iter2, s->partials, ctx->stream));
+        return DMF_OK;
+    }
     dmf::set_alpha_thread_per_sample(ctx->generic_level == 1 || ctx->generic_level == 2);
     HIP_TRY(dmf::launch_alpha_phase(s->gb, s->alpha, s->alpha_prev, s->state, (int)p->S, (int)p->n_c,
                                     (int)s->n_u, n_iter2, s->partials, ctx->stream));
@@ -673,6 +679,19 @@ int dmf_solver_step(dmf_solver* s, int64_t n_outer, int64_t n_iter2, double tol,
     return DMF_OK;
 }
 
+int dmf_solver_set_purity(dmf_solver* s, const double* purity, int flags) {
+    if (s == nullptr || purity == nullptr) return DMF_ERR_BAD_ARG;
+    dmf_context* ctx = s->ctx;
+    DMF_TRY(check_ctx(ctx));
+    if (s->mode != DMF_MODE_PARTIAL) return DMF_ERR_BAD_ARG;
+    const size_t bytes = (size_t)s->p->S * sizeof(double);
+    if (s->purity == nullptr) HIP_TRY(hipMalloc((void**)&s->purity, bytes));
+    const hipMemcpyKind kind = (flags & DMF_PTR_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIP_TRY(hipMemcpyAsync(s->purity, purity, bytes, kind, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DMF_OK;
+}
+
 int dmf_solver_get(dmf_solver* s, int flags, double* out_u, double* out_alpha, double* out_cost,
                    int64_t* out_iters) {
     if (s == nullptr) return DMF_ERR_BAD_ARG;
@@ -700,6 +719,7 @@ int dmf_solver_destroy(dmf_solver* s) {
     hipFree(s->slab);
     hipFree(s->partials);
     hipFree(s->u2_partials);
+    hipFree(s->purity);
     hipFree(s->state);
     if (s->h_state) hipHostFree(s->h_state);
     hipFree(s->job_k);

@@ -114,6 +114,9 @@ hipError_t launch_alpha_phase(const double* gb, double* alpha, double* alpha_pre
 // partials must hold 2 * max(ceil(S / 64), ceil(S * 32 / 64)) doubles (lane-parallel kernel: G lanes per sample)
 void set_alpha_thread_per_sample(bool on);
 hipError_t launch_set_lh(SolverState* state, hipStream_t st);
+// purity-constrained alpha phase (Frank-Wolfe, deconvolution.py:280-302) on the same packed Gram buffer
+hipError_t launch_alpha_frank_wolfe(const double* gb, double* alpha, const double* purity, SolverState* state,
+                                    int S, int n_c, int n_u, int max_iter, double* partials, hipStream_t st);
 hipError_t launch_project_simplex(const double* X, double* out, int K, int S, double z,
                                   hipStream_t st);
 hipError_t launch_scatter_known_block(const double* gb_known, double* gb, int n_c, int K, int S,

@@ -440,6 +440,81 @@ hipError_t launch_alpha_phase(const double* gb, double* alpha, double* alpha_pre
     return hipErrorInvalidValue;
 }
 
+// ---- purity-constrained alpha phase: Frank-Wolfe on the packed Gram data ----------------------------
+// demethify/deconvolution.py:280-302 (`frank_wolfe_nmf`): per sample, the known block keeps mass
+// purity[s] and the unknown block mass 1 - purity[s]; iteration k moves by 2 / (k + 2) towards the
+// vertex with the smallest gradient entry in each block.  grad = G a - b (= -R^T (d * (v - R a))).
+// One thread per sample; a[] in scratch for the runtime-K loop (secondary path, run time is dominated by
+// the row pass).
+__global__ __launch_bounds__(64) void k_alpha_frank_wolfe(const double* __restrict__ gb,
+                                                          double* __restrict__ alpha,
+                                                          const double* __restrict__ purity,
+                                                          const SolverState* __restrict__ state, int S, int K,
+                                                          int n_u, int max_iter, double* __restrict__ partials) {
+    if (state->done) return;
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    const bool active = s < S;
+    const int sc = active ? s : S - 1;
+    const int n_c = K - n_u;
+    const double* __restrict__ G = gb + sc;
+    const int64_t gs = S;
+    const double pur = purity[sc];
+    double a[kMaxK], grad[kMaxK];
+    for (int k = 0; k < K; ++k) a[k] = alpha[(int64_t)k * S + sc];
+    for (int it = 0; it < max_iter; ++it) {
+        for (int k = 0; k < K; ++k) grad[k] = -G[tri(k, K) * gs];
+        for (int l = 0; l < K; ++l)
+            for (int k = 0; k <= l; ++k) {
+                const double gkl = G[tri(k, l) * gs];
+                grad[k] = fma(gkl, a[l], grad[k]);
+                if (k != l) grad[l] = fma(gkl, a[k], grad[l]);
+            }
+        int i1 = 0, i2 = n_c;  // np.argmin: first index of the minimum
+        for (int k = 1; k < n_c; ++k)
+            if (grad[k] < grad[i1]) i1 = k;
+        for (int k = n_c + 1; k < K; ++k)
+            if (grad[k] < grad[i2]) i2 = k;
+        const double gamma = 2.0 / (double)(it + 2);
+        for (int k = 0; k < K; ++k) {
+            double vertex = 0.0;
+            if (k < n_c && k == i1) vertex = pur;
+            if (k >= n_c && k == i2) vertex = 1.0 - pur;
+            a[k] = (1.0 - gamma) * a[k] + gamma * vertex;
+        }
+    }
+    double cost = 0.0, n2 = 0.0;
+    if (active) {
+        cost = G[tri(K, K) * gs];
+        double lin = 0.0, quad = 0.0;
+        for (int l = 0; l < K; ++l) {
+            alpha[(int64_t)l * S + s] = a[l];
+            lin = fma(a[l], G[tri(l, K) * gs], lin);
+            double off = 0.0;
+            for (int k = 0; k < l; ++k) off = fma(G[tri(k, l) * gs], a[k], off);
+            quad = fma(a[l], fma(2.0, off, G[tri(l, l) * gs] * a[l]), quad);
+            if (l >= n_c) n2 = fma(a[l], a[l], n2);
+        }
+        cost = cost - 2.0 * lin + quad;
+    }
+    cost = wave_sum(cost);
+    n2 = wave_sum(n2);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = cost;
+        partials[2 * blockIdx.x + 1] = n2;
+    }
+}
+
+hipError_t launch_alpha_frank_wolfe(const double* gb, double* alpha, const double* purity, SolverState* state,
+                                    int S, int n_c, int n_u, int max_iter, double* partials, hipStream_t st) {
+    const int K = n_c + n_u;
+    if (K > kMaxK) return hipErrorInvalidValue;
+    const int nb = (S + 63) / 64;
+    hipLaunchKernelGGL(k_alpha_frank_wolfe, dim3(nb), dim3(64), 0, st, gb, alpha, purity, state, S, K, n_u, max_iter,
+                       partials);
+    hipLaunchKernelGGL(k_finish_iteration, dim3(1), dim3(64), 0, st, partials, nb, state, max_iter);
+    return hipGetLastError();
+}
+
 // ---- standalone projection (KAT entry point) ----------------------------------------------
 template <int KMAX>
 __global__ __launch_bounds__(64) void k_project(const double* __restrict__ X, double* __restrict__ out,

@@ -20,7 +20,8 @@ from .init_func import wls_intercept
 
 __all__ = [
     "set_seed", "cost_f_w", "projection_simplex_sort_2d", "init_BSSMF_md", "update_u", "update_alpha",
-    "unsupervised_deconv", "mdwbssmf_deconv", "wls_intercept", "solve_problem",
+    "unsupervised_deconv", "mdwbssmf_deconv", "wls_intercept", "solve_problem", "init_BSSMF_md_p",
+    "mdwbssmf_deconv_p",
 ]
 
 _OUT_OF_SCOPE_INITS = ("ICA", "SVD")
@@ -99,9 +100,12 @@ def update_alpha(n_iter2, alpha, a2, l_h_, l_h, alpha_, R, d_x, meth_frequency):
         return p.update_alpha(last, alpha, alpha_, n_iter2, a2, l_h_, l_h)
 
 
-def solve_problem(problem: Problem, u0, alpha0, mode, n_iter1, n_iter2, tol, return_info=False):
-    """Run the outer loop on a device-resident problem -> (u, alpha[, cost, iterations])."""
+def solve_problem(problem: Problem, u0, alpha0, mode, n_iter1, n_iter2, tol, return_info=False, purity=None):
+    """Run the outer loop on a device-resident problem -> (u, alpha[, cost, iterations]).
+    ``purity`` (per-sample mass of the known block) selects the purity-constrained alpha phase."""
     with Solver(problem, u0, alpha0, mode) as s:
+        if purity is not None:
+            s.set_purity(purity)
         s.step(n_iter1, n_iter2, tol)
         u, alpha, cost, iters = s.get()
     if return_info:
@@ -116,6 +120,49 @@ def mdwbssmf_deconv(u, R, alpha, meth_frequency, d_x, R_trunc, n_u, n_iter1=1000
     with Problem(get_context(), meth_frequency, d_x, R_trunc) as p:
         return solve_problem(p, np.asarray(u).reshape(-1, n_u), alpha, L.DMF_MODE_PARTIAL, n_iter1, n_iter2,
                              tol)
+
+
+def init_BSSMF_md_p(init_option, meth_frequency, d_x, R_trunc, n_u, purity, rb_alg=wls_intercept, seed=None):
+    """deconvolution.py:228-267 -> (u, R, alpha): as init_BSSMF_md but without the zero guard on the first
+    unknown row (the function returns right after building R); ``purity`` only matters to the SVD / ICA
+    initialisers, which are outside this build."""
+    del purity
+    set_seed(seed)
+    nb = meth_frequency.shape[1]
+    n_rows, n_c = R_trunc.shape
+    if init_option != "uniform" and n_u > nb:
+        print("The number of unknowns is greater than the number of samples, we'll go with a uniform initialisation. ")
+        init_option = "uniform"
+    if init_option != "uniform_" and n_u > nb:
+        init_option = "uniform_"
+    if init_option in _OUT_OF_SCOPE_INITS:
+        raise NotImplementedError(
+            f"--init {init_option} (one-shot LAPACK initialiser, demethify/init_func.py) is not part of "
+            "this build; use uniform_, uniform or beta")
+    if init_option == "uniform":
+        u = rd.uniform(size=(n_rows, n_u))
+        stacked = np.c_[R_trunc, u]
+        alpha = np.concatenate(
+            [rb_alg(meth_frequency[:, k:k + 1], d_x[:, k:k + 1], stacked) for k in range(nb)], axis=1)
+    elif init_option == "uniform_":
+        u = rd.uniform(size=(n_rows, n_u))
+        alpha = rd.dirichlet(np.ones(n_c + n_u), nb).T
+    elif init_option == "beta":
+        shape = np.ones((n_rows, n_u)) * 0.5
+        u = rd.beta(shape, shape)
+        alpha = rd.dirichlet(np.ones(n_c + n_u), nb).T
+    else:
+        raise UnboundLocalError(f"unknown init option {init_option!r}")
+    return u, np.c_[R_trunc, u], alpha
+
+
+def mdwbssmf_deconv_p(u, R, alpha, meth_frequency, d_x, R_trunc, n_u, purity, n_iter1=100, n_iter2=500, tol=1e-3):
+    """deconvolution.py:306-337 -> (u, alpha): u phase as mdwbssmf_deconv, alpha phase = Frank-Wolfe with the
+    known block of sample s at mass purity[s] and the unknown block at 1 - purity[s] (:280-302)."""
+    del R
+    with Problem(get_context(), meth_frequency, d_x, R_trunc) as p:
+        return solve_problem(p, np.asarray(u).reshape(-1, n_u), alpha, L.DMF_MODE_PARTIAL, n_iter1, n_iter2,
+                             tol, purity=purity)
 
 
 def _init_unsupervised(init_option, meth_frequency, n_u, seed):

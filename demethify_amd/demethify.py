@@ -9,7 +9,7 @@ Restarts, bootstrap replicates and model-selection candidates are then sharded o
 Deliberate differences from upstream, all flagged at run time:
   * ``--restart r``: upstream re-runs the SAME seed r times; here restart k > 0 uses seed + k
     (restart 0 is bit-compatible), SURVEY.md section 8b.
-  * ``--purity``, ``--plot`` and ``--init SVD|ICA`` are outside this build's scope and exit with a message.
+  * ``--plot`` is ignored with a note and ``--init SVD|ICA`` exits with a message (outside this build's scope).
 """
 from __future__ import annotations
 
@@ -109,9 +109,15 @@ def main(argv=None):
         args.iterations = [100, 500] if args.purity else [10000, 20]
     if isinstance(args.termination, list):
         args.termination = args.termination[0]
-    if args.purity:
-        sys.stderr.write("Error: --purity (purity-constrained solver, deconvolution.py:228-337) is not part of this build.\n")
-        sys.exit(1)
+    purity = None
+    if args.purity:  # demethify.py:69-77
+        purity = np.array(args.purity)
+        if np.any((purity >= 0) & (purity <= 1)):
+            print("Purity is between 0 and 1, are you sure that it's a percentage?")
+        elif np.any((purity < 0) & (purity > 100)):
+            sys.stderr.write("Error: Invalid value for purity, not within [0,100] bounds.")
+            sys.exit(1)
+        purity = 1 - (purity / 100.0)
     nb_r = 5
     if args.ic:
         if args.nbunknown:
@@ -120,6 +126,10 @@ def main(argv=None):
         if len(args.ic) > 1:
             nb_r = int(args.ic[1])
         args.ic = args.ic[0]
+    if args.init in ("SVD", "ICA"):
+        sys.stderr.write(f"Error: --init {args.init} (one-shot LAPACK initialiser, demethify/init_func.py) is not part "
+                         "of this build; use uniform_, uniform or beta.\n")
+        sys.exit(1)
     if args.plot:
         sys.stderr.write("Note: --plot is ignored, plotting (seaborn/colorcet) is outside this build's scope.\n")
 
@@ -140,7 +150,7 @@ def main(argv=None):
     from . import _lib as L
     from . import shard
     from .bootstrap import bt_ci
-    from .deconvolution import _init_unsupervised, init_BSSMF_md, solve_problem
+    from .deconvolution import _init_unsupervised, init_BSSMF_md, init_BSSMF_md_p, solve_problem
     from .device import Problem, get_context
     from .ic import evaluate_best_ic
     from .init_func import wls_intercept
@@ -172,10 +182,15 @@ def main(argv=None):
                 if unsupervised:
                     u0, a0 = _init_unsupervised(args.init, meth_f, n_u, seed_k)
                     mode = L.DMF_MODE_UNSUPERVISED
+                elif purity is not None:
+                    u0, _, a0 = init_BSSMF_md_p(args.init, meth_f, counts, ref, n_u, purity, rb_alg=wls_intercept,
+                                                seed=seed_k)
+                    mode = L.DMF_MODE_PARTIAL
                 else:
                     u0, _, a0 = init_BSSMF_md(args.init, meth_f, counts, ref, n_u, rb_alg=wls_intercept, seed=seed_k)
                     mode = L.DMF_MODE_PARTIAL
-                u, alpha = solve_problem(problem, u0, a0, mode, args.iterations[0], args.iterations[1], args.termination)
+                u, alpha = solve_problem(problem, u0, a0, mode, args.iterations[0], args.iterations[1], args.termination,
+                                         purity=None if unsupervised else purity)
                 return u, alpha, problem.cost(u, alpha)  # cost_f_w recomputed per restart, demethify.py:169,199
 
             ref_estimate, proportions, _best, _costs = shard.sharded_restarts(

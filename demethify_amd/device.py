@@ -241,6 +241,14 @@ class Solver:
                                             int(mode), 0, C.byref(h)), "dmf_solver_create")
         self._h = h
 
+    def set_purity(self, purity):
+        """Switch the alpha phase to the purity-constrained Frank-Wolfe update (deconvolution.py:280-302):
+        per-sample mass of the known block, S values in [0, 1]."""
+        purity = np.ascontiguousarray(purity, dtype=np.float64).ravel()
+        if purity.shape != (self.problem.S,):
+            raise ValueError(f"purity needs one value per sample ({self.problem.S}), got {purity.shape}")
+        L.check(self._lib.dmf_solver_set_purity(self._h, _ptr(purity), 0), "dmf_solver_set_purity")
+
     def step(self, n_outer: int, n_iter2: int, tol: float):
         """Run up to n_outer outer iterations; returns (total iterations so far, converged)."""
         it, conv = C.c_int64(), C.c_int()

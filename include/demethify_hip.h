@@ -124,6 +124,11 @@ int dmf_update_alpha(dmf_context* ctx, const dmf_problem* p, const double* u, in
  * |cf - cf_0| < tol (:220); get = copy out the current (u, alpha). */
 int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0,
                       const double* alpha0, int64_t n_u, int mode, int flags, dmf_solver** out);
+/* Purity-constrained variant (mdwbssmf_deconv_p, deconvolution.py:306-337): after this call the alpha
+ * phase of every step is Frank-Wolfe (frank_wolfe_nmf, :280-302) with the known block of sample s held at
+ * mass purity[s] and the unknown block at 1 - purity[s]; n_iter2 of dmf_solver_step is then also the
+ * number of Frank-Wolfe iterations.  purity: S doubles.  Partial-reference mode only. */
+int dmf_solver_set_purity(dmf_solver* s, const double* purity, int flags);
 int dmf_solver_step(dmf_solver* s, int64_t n_outer, int64_t n_iter2, double tol,
                     int64_t* iters_done_total, int* converged);
 int dmf_solver_get(dmf_solver* s, int flags, double* out_u, double* out_alpha,

@@ -329,3 +329,77 @@ def synthetic_problem(N, S, n_c, n_u, seed=0, depth=50):
     X = rs.binomial(D, np.clip(Rfull @ A, 0, 1))
     V = X / D
     return V, D.astype(np.int64), np.ascontiguousarray(Rfull[:, :n_c])
+
+
+# ---------------------------------------------------------------- purity-constrained variant
+
+def init_partial_purity(init_option, V, D, Rt, n_u, purity, seed=None):
+    """demethify/deconvolution.py:228-267 (`init_BSSMF_md_p`), options uniform_/beta/uniform: as
+    init_partial but without the first-unknown-row guard (:265-267 returns right after np.c_)."""
+    set_seed(seed)
+    S = V.shape[1]
+    N, n_c = Rt.shape
+    if init_option != "uniform" and n_u > S:
+        print("The number of unknowns is greater than the number of samples, we'll go with a uniform initialisation. ")
+        init_option = "uniform"
+    if init_option != "uniform_" and n_u > S:
+        init_option = "uniform_"
+    if init_option == "uniform":
+        u = rd.uniform(size=(N, n_u))
+        full = np.c_[Rt, u]
+        alpha = np.concatenate(
+            [nnls_intercept_proportions(V[:, k:k + 1], D[:, k:k + 1], full) for k in range(S)], axis=1)
+    elif init_option == "uniform_":
+        u = rd.uniform(size=(N, n_u))
+        alpha = rd.dirichlet(np.ones(n_c + n_u), S).T
+    elif init_option == "beta":
+        half = np.ones((N, n_u)) * 0.5
+        u = rd.beta(half, half)
+        alpha = rd.dirichlet(np.ones(n_c + n_u), S).T
+    else:
+        raise NotImplementedError(f"init option {init_option!r} is outside the oracle's scope")
+    return u, np.c_[Rt, u], alpha
+
+
+def frank_wolfe_alpha(W1, W2, V, alpha1, alpha2, purity, max_iter, D):
+    """demethify/deconvolution.py:280-302 (`frank_wolfe_nmf`): the known block of every column keeps mass
+    purity[col], the unknown block mass 1 - purity[col]; step 2 / (k + 2) towards the best vertex."""
+    alpha1 = alpha1.copy()
+    alpha2 = alpha2.copy()
+    cols = np.arange(alpha1.shape[1])
+    for k in range(max_iter):
+        resid = D * (V - W1 @ alpha1 - W2 @ alpha2)
+        grad1 = -W1.T @ resid
+        grad2 = -W2.T @ resid
+        s1 = np.zeros_like(alpha1)
+        s2 = np.zeros_like(alpha2)
+        s1[np.argmin(grad1, axis=0), cols] = purity
+        s2[np.argmin(grad2, axis=0), cols] = 1 - purity
+        gamma = 2 / (k + 2)
+        alpha1 = (1 - gamma) * alpha1 + gamma * s1
+        alpha2 = (1 - gamma) * alpha2 + gamma * s2
+    return alpha1, alpha2
+
+
+def solve_partial_purity(u, R, alpha, V, D, Rt, n_u, purity, n_iter1=100, n_iter2=500, tol=1e-3, trace=None):
+    """demethify/deconvolution.py:306-337 (`mdwbssmf_deconv_p`)."""
+    a1 = 1.0
+    u_ = u.copy()
+    alpha1, alpha2 = alpha[:-n_u], alpha[-n_u:]
+    d = D.max() ** 2
+    l_w = (np.linalg.norm(alpha2) ** 2) * d
+    l_w_ = l_w
+    cf = weighted_cost(V, R, alpha, D)
+    for _ in range(n_iter1):
+        cf_0 = cf
+        u, u_, a1, l_w_ = u_phase(u, alpha, n_iter2, a1, l_w_, l_w, u_, V, Rt, n_u, D)
+        R = np.hstack((Rt, u.reshape(-1, n_u)))
+        alpha1, alpha2 = frank_wolfe_alpha(Rt, u, V, alpha1, alpha2, purity, n_iter2, D)
+        l_w = (np.linalg.norm(alpha2) ** 2) * d
+        alpha = np.vstack((alpha1, alpha2))
+        cf = weighted_cost(V, R, alpha, D)
+        if trace is not None:
+            trace.append(cf)
+        if abs(cf - cf_0) < tol:
+            break
+    return u, alpha

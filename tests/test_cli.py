@@ -67,7 +67,7 @@ def test_argument_errors(tmp_path):
                 "--nbunknown", "2", expect=1)
     assert "--ic cannot be used with --nbunknown" in p.stderr
     p = run_cli("--ref", REF, "--methfreq", *SAMPLES, "--bedmethyl", "--outdir", str(tmp_path), "--nbunknown", "1",
-                "--purity", "60", "80", expect=1)
+                "--init", "SVD", expect=1)
     assert "not part of this build" in p.stderr
     run_cli("--methfreq", *SAMPLES, expect=2)  # --outdir is required
 
@@ -94,6 +94,17 @@ def test_partial_reference_command_reproduces_committed_outputs(tmp_path):
     got = pd.read_csv(tmp_path / "methylation_profile_estimate.csv")
     want = pd.read_csv(UPSTREAM / "output_partial_ref" / "methylation_profile_estimate.csv")
     assert list(got.columns) == ["unknown_cell_1"] and np.abs(got.values - want.values).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_purity_command_reproduces_committed_outputs(tmp_path):
+    """README 'Partial-reference based case with purity' (test/purity): Frank-Wolfe alpha phase, 100 x 500."""
+    run_cli("--ref", REF, "--methfreq", *SAMPLES, "--nbunknown", "1", "--purity", "60", "80", "90", "20", "50", "90",
+            "100", "30", "50", "10", "--bedmethyl", "--outdir", str(tmp_path), "--noprint")
+    same_csv(tmp_path / "celltypes_proportions.csv", UPSTREAM / "purity" / "celltypes_proportions.csv", 1e-8)
+    got = pd.read_csv(tmp_path / "methylation_profile_estimate.csv")
+    want = pd.read_csv(UPSTREAM / "purity" / "methylation_profile_estimate.csv")
+    assert np.abs(got.values - want.values).max() < 1e-8
 
 
 @pytest.mark.gpu

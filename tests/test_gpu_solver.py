@@ -117,6 +117,26 @@ def test_many_unknowns_uses_fallback_path(ctx):
     assert rel_err(ga, wa) < TIGHT and np.abs(gu - wu).max() < TIGHT
 
 
+@pytest.mark.parametrize("generic", [0, 1, 3])
+def test_purity_constrained_solver(ctx, generic):
+    """mdwbssmf_deconv_p: same u phase, Frank-Wolfe alpha phase; fixed iteration count on synthetic data."""
+    from demethify_amd import deconvolution as dd
+
+    V, D, Rt = osol.synthetic_problem(1500, 12, 4, 2, seed=13, depth=25)
+    purity = np.linspace(0.2, 0.9, 12)
+    u0, R, a0 = osol.init_partial_purity("uniform_", V, D, Rt, 2, purity, seed=5)
+    wu, wa = osol.solve_partial_purity(u0.copy(), R, a0.copy(), V, D, Rt, 2, purity, 4, 30, 0.0)
+    gu0, gR, ga0 = dd.init_BSSMF_md_p("uniform_", V, D, Rt, 2, purity, seed=5)
+    assert np.array_equal(gu0, u0) and np.array_equal(ga0, a0)
+    ctx.set_generic(generic)
+    try:
+        gu, ga = dd.mdwbssmf_deconv_p(gu0, gR, ga0, V, D, Rt, 2, purity, n_iter1=4, n_iter2=30, tol=0.0)
+    finally:
+        ctx.set_generic(0)
+    assert rel_err(ga, wa) < TIGHT and np.abs(gu - wu).max() < TIGHT
+    assert np.allclose(ga[:4].sum(axis=0), purity, atol=1e-12) and np.allclose(ga[4:].sum(axis=0), 1 - purity, atol=1e-12)
+
+
 def test_inputs_are_not_mutated(toy):
     from demethify_amd import deconvolution as dd
 

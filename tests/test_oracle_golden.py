@@ -30,6 +30,18 @@ def test_unsupervised_folder(toy):
     assert np.abs(u - read_profile("unsupervised")).max() < 1e-11
 
 
+def test_purity_folder(toy):
+    """README purity command: --purity 60 80 90 20 50 90 100 30 50 10 -> 1 - p/100 (demethify.py:77)."""
+    V, D, ref, _ = toy
+    purity = 1 - np.array([60, 80, 90, 20, 50, 90, 100, 30, 50, 10]) / 100.0
+    u, R, alpha = osol.init_partial_purity("uniform_", V, D, ref, 1, purity, seed=1)
+    trace = []
+    u, alpha = osol.solve_partial_purity(u, R, alpha, V, D, ref, 1, purity, 100, 500, 1e-2, trace=trace)
+    assert len(trace) == 7
+    assert np.abs(alpha - read_props("purity")).max() < 1e-12
+    assert np.abs(u - read_profile("purity")).max() < 1e-12
+
+
 def test_reference_based_folder(toy):
     V, D, ref, _ = toy
     alpha = np.concatenate(
