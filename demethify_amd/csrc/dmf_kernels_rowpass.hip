@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_u_phase_gram(
 bool u_phase_gram_supported(int S, int n_c, int n_u) {
     (void)S;
     (void)n_c;
-    return n_u >= 1 && n_u <= 8;
+    return n_u >= 1 && n_u <= 16;  // 9..16: c and M (up to 152 doubles) still fit the register file
 }
 
 template <int NU>
@@ -148,6 +148,7 @@ hipError_t launch_u_phase_gram(const double* V, const double* D, const double* R
 #define DMF_CASE(NU_) \
     case NU_: return launch_u_gram_t<NU_>(V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, st);
         DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4) DMF_CASE(5) DMF_CASE(6) DMF_CASE(7) DMF_CASE(8)
+        DMF_CASE(9) DMF_CASE(10) DMF_CASE(11) DMF_CASE(12) DMF_CASE(13) DMF_CASE(14) DMF_CASE(15) DMF_CASE(16)
 #undef DMF_CASE
         default: return hipErrorInvalidValue;
     }

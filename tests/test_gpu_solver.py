@@ -54,7 +54,7 @@ def test_stop_iteration_matches_oracle(toy, ctx):
 
 CASES = [  # (N, S, n_c, n_u, T1)
     (4096, 7, 6, 1, 6), (4096, 64, 6, 2, 6), (4096, 100, 6, 4, 5), (3000, 33, 0, 2, 6), (2500, 64, 0, 4, 5),
-    (1111, 130, 12, 4, 4), (900, 20, 3, 8, 4),
+    (1111, 130, 12, 4, 4), (900, 20, 3, 8, 4), (700, 12, 0, 12, 3), (600, 16, 2, 16, 3),
 ]
 
 
