@@ -301,17 +301,32 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
     if (s->use_fused) {
-        int grid = 0;
+        // The fused kernel takes whole 16-row blocks; a ragged tail (< 16 rows) goes through the unfused
+        // pair on offset pointers and contributes extra slab rows and one more ||u||^2 share.
+        const int64_t n_full = p->N - (p->N & 15), n_tail = p->N - n_full;
+        const int S = (int)p->S, n_c = (int)p->n_c, n_u = (int)s->n_u, nct = (n_c + 3) / 4 * 4;
+        int grid = 0, ny_tail = 0;
         {
             FamilyScope scope(ctx, DMF_KERNEL_ROWPASS);
-            HIP_TRY(dmf::launch_rowpass_fused(p->V, p->D, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N,
-                                              (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, s->slab,
-                                              s->u2_partials, &grid, ctx->stream));
+            HIP_TRY(dmf::launch_rowpass_fused(p->V, p->D, p->Rtp, s->alpha, s->u, s->u_prev, s->state, n_full, S, n_c,
+                                              n_u, n_iter2, s->mode, s->slab, s->u2_partials, &grid, ctx->stream));
         }
-        HIP_TRY(dmf::launch_finish_u_norm(s->u2_partials, grid, s->state, ctx->stream));
+        if (n_tail > 0) {
+            const double* rt_tail = p->Rtp ? p->Rtp + n_full * nct : nullptr;
+            double* u_tail = s->u + n_full * n_u;
+            HIP_TRY(dmf::launch_u_phase_mfma(p->V + n_full * S, p->D + n_full * S, rt_tail, s->alpha, u_tail,
+                                             s->u_prev + n_full * n_u, s->state, n_tail, S, n_c, n_u, n_iter2,
+                                             s->mode, ctx->stream));
+            HIP_TRY(dmf::launch_sumsq_f64(u_tail, n_tail * n_u, ctx->scratch, s->u2_partials + grid, &s->state->done,
+                                          ctx->stream));
+            HIP_TRY(dmf::launch_gram_u(p->V + n_full * S, p->D + n_full * S, rt_tail, u_tail, n_tail, S, n_c, n_u,
+                                       s->slab + (int64_t)2 * grid * s->n_jobs * S, &s->state->done, &ny_tail,
+                                       ctx->stream));
+        }
+        HIP_TRY(dmf::launch_finish_u_norm(s->u2_partials, grid + (n_tail > 0 ? 1 : 0), s->state, ctx->stream));
         {
             FamilyScope scope(ctx, DMF_KERNEL_GRAM);
-            HIP_TRY(dmf::launch_gram_reduce(s->slab, 2 * grid, s->n_jobs, (int)p->S, s->job_dst, s->gb,
+            HIP_TRY(dmf::launch_gram_reduce(s->slab, 2 * grid + ny_tail, s->n_jobs, S, s->job_dst, s->gb,
                                             &s->state->done, ctx->stream));
         }
         DMF_TRY(enqueue_alpha_phase(s, n_iter2));
@@ -583,8 +598,9 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     else if (ctx->generic_level != 2 && dmf::u_phase_gram_supported((int)S, (int)n_c, (int)n_u)) s->u_path = 1;
     else s->u_path = 2;
     s->use_gram_spec = fast && dmf::gram_u_supported((int)n_c, (int)n_u);
-    s->use_fused = ctx->generic_level == 0 && p->d_f32_exact &&
-                   dmf::rowpass_fused_supported((int)S, (int)n_c, (int)n_u);
+    s->use_fused = ctx->generic_level == 0 && p->d_f32_exact && N >= 16 &&
+                   dmf::rowpass_fused_supported((int)S, (int)n_c, (int)n_u) &&
+                   dmf::u_phase_mfma_supported((int)S, (int)n_c, (int)n_u) && dmf::gram_u_supported((int)n_c, (int)n_u);
     if (s->u_path == 2 && !dmf::u_step_direct_supported((int)S, (int)n_c, (int)n_u)) {
         delete s;
         return DMF_ERR_UNSUPPORTED;
@@ -607,7 +623,8 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
         if (spec > s->slab_doubles) s->slab_doubles = spec;
     }
     if (s->use_fused) {
-        const int64_t spec = dmf::rowpass_fused_slab_doubles(N, (int)S, (int)n_c, (int)n_u);
+        const int64_t spec = dmf::rowpass_fused_slab_doubles(N - (N & 15), (int)S, (int)n_c, (int)n_u) +
+                             dmf::gram_u_slab_doubles(16, (int)S, (int)n_c, (int)n_u);  // + ragged tail rows
         if (spec > s->slab_doubles) s->slab_doubles = spec;
     }
     const size_t un = (size_t)N * n_u * sizeof(double), an = (size_t)K * S * sizeof(double);

@@ -14,8 +14,9 @@
 // At the end every workgroup stores its accumulators as one slab (job order of the solver's table) and
 // its share of ||u||_F^2; k_gram_reduce sums the slabs in fixed order.
 //
-// Preconditions (checked by the launcher): S % 4 == 0, S <= 256, n_c <= 16, n_u <= 8; `Rtp` is the
-// problem's zero-padded copy of R_trunc (row stride 4 NKC).
+// Preconditions (checked by the launcher): N % 16 == 0 (the caller runs the ragged tail, < 16 rows, through
+// the unfused kernels), S % 4 == 0, S <= 256, n_c <= 16, n_u <= 8, counts exactly representable in f32;
+// `Rtp` is the problem's zero-padded copy of R_trunc (row stride 4 NKC).
 #include "dmf_device.h"
 #include "dmf_internal.h"
 
@@ -44,6 +45,10 @@ __device__ __forceinline__ unsigned long long dmf_stamp() {
 #endif
 
 #define DMF_WAVES_PER_WG(NW) (3 * (NW))  // A team (NW waves) + C team (2 NW waves)
+#ifndef DMF_C_ROWS_BEFORE_X
+#define DMF_C_ROWS_BEFORE_X 4
+#endif
+constexpr int kCRowsBeforeX = DMF_C_ROWS_BEFORE_X;  // of a C wave's 8 rows per block, how many run before barrier X
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
     }
     __syncthreads();
 
-    const int64_t nblk = (N + 15) / 16;
+    const int64_t nblk = N / 16;  // N % 16 == 0 (launcher's contract)
     const int nk = (int)((nblk - blockIdx.x + gridDim.x - 1) / gridDim.x);  // blocks of this workgroup
 
     if (a_team) {
@@ -191,16 +196,21 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
         double nrt[NKC > 0 ? NKC : 1];
         // (small loads first: vmcnt retires in order, so nothing issued after the 16 tile loads may be
         // waited on before the next step)
+        // N is a multiple of 16 here (the launcher hands the ragged tail to the unfused kernels), so every
+        // address is a wave-uniform 64-bit base plus a per-lane 32-bit offset: no clamps, no 64-bit multiplies.
+        const int lane_tile_off = ld_row * S + ld_gcol;
+        const int lane_rt_off = m16 * NCT + q;
         auto prefetch = [&](int64_t blk) {
             const int64_t r0 = blk * 16;
-            const int64_t rowc = r0 + m16 < N ? r0 + m16 : N - 1;
+            const double* __restrict__ rb = Rtp + r0 * NCT;
 #pragma unroll
-            for (int kc = 0; kc < NKC; ++kc) nrt[kc] = Rtp[rowc * NCT + kc * 4 + q];
+            for (int kc = 0; kc < NKC; ++kc) nrt[kc] = rb[lane_rt_off + kc * 4];
+            const double* __restrict__ vb = V + r0 * S;
+            const double* __restrict__ db = D + r0 * S;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int64_t gr = r0 + 2 * i + ld_row < N ? r0 + 2 * i + ld_row : N - 1;
-                pv[i] = *reinterpret_cast<const v2d*>(V + gr * S + ld_gcol);
-                pd[i] = *reinterpret_cast<const v2d*>(D + gr * S + ld_gcol);
+                pv[i] = *reinterpret_cast<const v2d*>(vb + (2 * i) * S + lane_tile_off);
+                pd[i] = *reinterpret_cast<const v2d*>(db + (2 * i) * S + lane_tile_off);
             }
         };
         prefetch(blockIdx.x);
@@ -211,7 +221,6 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
             if (s < nk) {
                 const int64_t blk = blockIdx.x + (int64_t)s * gridDim.x;
                 const int64_t row0 = blk * 16;
-                const int nvalid = N - row0 < 16 ? (int)(N - row0) : 16;
                 char* __restrict__ tile = tile_of(s & 1);
                 double* __restrict__ tileV = reinterpret_cast<double*>(tile);
                 float* __restrict__ tileD = reinterpret_cast<float*>(tile + kTileVBytes);
@@ -237,56 +246,99 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                 const bool my_turn = wave == s % NW;
                 // (unconditional on purpose: loads under a branch make the compiler's s_waitcnt placement
                 // pessimistic at the join and stall on the fresh prefetch)
-                const bool ok0 = rl < RPW && rl < nvalid;
+                const bool ok0 = rl < RPW && rl < 16;
                 const int64_t gi0 = ok0 ? (row0 + rl) * NU + j : 0;
                 const double uu0 = u[gi0];
                 const double up0 = u_prev[gi0];
-                prefetch(s + 1 < nk ? blk + gridDim.x : blk);
                 __builtin_amdgcn_wave_barrier();
-                DMF_STAMP(0)  // tile store + prefetch issue
+                DMF_STAMP(0)  // tile store
 
-                // ---- phase A: MFMA contractions on the tile, row-on-lane layout
-                v4d cacc = {0.0, 0.0, 0.0, 0.0};
-                v4d macc[NMT];
-#pragma unroll
-                for (int mt = 0; mt < NMT; ++mt) macc[mt] = cacc;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                // ---- phase A: MFMA contractions on the tile, row-on-lane layout.  The LDS reads of strip
+                // t + 1 (tile values and alpha operands) are issued before the MFMAs of strip t, so that one
+                // A wave per SIMD does not expose an LDS round trip in front of every MFMA group.
+                struct Strip {
+                    v2d v01, v23;
+                    v4f df;
+                    double a1v[NKC > 0 ? NKC : 1];
+                    v2d a2lo, a2hi;
+                    v2d jlo[NMT], jhi[NMT], llo[NMT], lhi[NMT];
+                };
+                auto load_strip = [&](int t, Strip& R) {
                     const double* __restrict__ tv = tileV + m16 * kTileRowDoubles + t * 16 + 4 * q;
-                    const v2d v01 = *reinterpret_cast<const v2d*>(tv), v23 = *reinterpret_cast<const v2d*>(tv + 2);
-                    const v4f df = *reinterpret_cast<const v4f*>(tileD + m16 * kTileRowFloats + t * 16 + 4 * q);
-                    v4d e = {v01.x, v01.y, v23.x, v23.y};
-                    const v4d d = {(double)df.x, (double)df.y, (double)df.z, (double)df.w};
+                    R.v01 = *reinterpret_cast<const v2d*>(tv);
+                    R.v23 = *reinterpret_cast<const v2d*>(tv + 2);
+                    R.df = *reinterpret_cast<const v4f*>(tileD + m16 * kTileRowFloats + t * 16 + 4 * q);
 #pragma unroll
-                    for (int kc = 0; kc < NKC; ++kc)
-                        e = __builtin_amdgcn_mfma_f64_16x16x4f64(alds[(kc * 4 + q) * AS + e_col + 16 * t], rtop[kc], e,
-                                                                 0, 0, 0);
-                    const v4d w = d * e;
+                    for (int kc = 0; kc < NKC; ++kc) R.a1v[kc] = alds[(kc * 4 + q) * AS + e_col + 16 * t];
                     // operand rows: this lane's four samples are contiguous and 16-B aligned in alds
                     const int col = k_col + 16 * t;
-                    const v2d a2lo = *reinterpret_cast<const v2d*>(alds + a2_row * AS + col);
-                    const v2d a2hi = *reinterpret_cast<const v2d*>(alds + a2_row * AS + col + 2);
-                    const double a2v[4] = {a2lo.x, a2lo.y, a2hi.x, a2hi.y};
-                    double pv4[NMT][4];
+                    R.a2lo = *reinterpret_cast<const v2d*>(alds + a2_row * AS + col);
+                    R.a2hi = *reinterpret_cast<const v2d*>(alds + a2_row * AS + col + 2);
 #pragma unroll
                     for (int mt = 0; mt < NMT; ++mt) {
-                        const v2d jlo = *reinterpret_cast<const v2d*>(alds + jp_row[mt] * AS + col);
-                        const v2d jhi = *reinterpret_cast<const v2d*>(alds + jp_row[mt] * AS + col + 2);
-                        const v2d llo = *reinterpret_cast<const v2d*>(alds + lp_row[mt] * AS + col);
-                        const v2d lhi = *reinterpret_cast<const v2d*>(alds + lp_row[mt] * AS + col + 2);
-                        pv4[mt][0] = jlo.x * llo.x;
-                        pv4[mt][1] = jlo.y * llo.y;
-                        pv4[mt][2] = jhi.x * lhi.x;
-                        pv4[mt][3] = jhi.y * lhi.y;
+                        R.jlo[mt] = *reinterpret_cast<const v2d*>(alds + jp_row[mt] * AS + col);
+                        R.jhi[mt] = *reinterpret_cast<const v2d*>(alds + jp_row[mt] * AS + col + 2);
+                        R.llo[mt] = *reinterpret_cast<const v2d*>(alds + lp_row[mt] * AS + col);
+                        R.lhi[mt] = *reinterpret_cast<const v2d*>(alds + lp_row[mt] * AS + col + 2);
                     }
+                };
+                // Two accumulator sets (even / odd k-steps): a dependent FP64 MFMA issued right behind its
+                // producer stalls for most of the producer's latency, four-plus independent chains do not.
+                v4d cacc = {0.0, 0.0, 0.0, 0.0}, cacc1 = cacc;
+                v4d macc[NMT], macc1[NMT];
+#pragma unroll
+                for (int mt = 0; mt < NMT; ++mt) macc[mt] = macc1[mt] = cacc;
+                // first product of a strip: E = V - Rt a_known (a chain of NKC dependent MFMAs)
+                auto e_init = [&](const Strip& R) { return v4d{R.v01.x, R.v01.y, R.v23.x, R.v23.y}; };
+                // c / M products of strip R (8 MFMAs on two accumulators) with the E chain of the NEXT strip
+                // slotted between them, so that no MFMA waits on the result of the one issued just before it
+                auto run_strip = [&](const Strip& R, v4d e, const Strip& Rn, bool has_next) {
+                    const v4d d = {(double)R.df.x, (double)R.df.y, (double)R.df.z, (double)R.df.w};
+                    const v4d w = d * e;
+                    const double a2v[4] = {R.a2lo.x, R.a2lo.y, R.a2hi.x, R.a2hi.y};
+                    v4d en = e_init(Rn);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2v[r], w[r], cacc, 0, 0, 0);
+                        if (r & 1) cacc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2v[r], w[r], cacc1, 0, 0, 0);
+                        else cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2v[r], w[r], cacc, 0, 0, 0);
 #pragma unroll
-                        for (int mt = 0; mt < NMT; ++mt)
-                            macc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(pv4[mt][r], d[r], macc[mt], 0, 0, 0);
+                        for (int mt = 0; mt < NMT; ++mt) {
+                            const double pj = r == 0 ? R.jlo[mt].x : r == 1 ? R.jlo[mt].y : r == 2 ? R.jhi[mt].x : R.jhi[mt].y;
+                            const double pl = r == 0 ? R.llo[mt].x : r == 1 ? R.llo[mt].y : r == 2 ? R.lhi[mt].x : R.lhi[mt].y;
+                            if (r & 1) macc1[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(pj * pl, d[r], macc1[mt], 0, 0, 0);
+                            else macc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(pj * pl, d[r], macc[mt], 0, 0, 0);
+                        }
+                        if (has_next && r < NKC) en = __builtin_amdgcn_mfma_f64_16x16x4f64(Rn.a1v[r], rtop[r], en, 0, 0, 0);
                     }
-                }
+                    if (has_next) {
+#pragma unroll
+                        for (int kc = 4; kc < NKC; ++kc)  // NKC <= 4: never runs; kept for clarity
+                            en = __builtin_amdgcn_mfma_f64_16x16x4f64(Rn.a1v[kc], rtop[kc], en, 0, 0, 0);
+                    }
+                    return en;
+                };
+                Strip sa, sb;
+                load_strip(0, sa);
+                load_strip(1, sb);
+                __builtin_amdgcn_sched_barrier(0);
+                v4d e0 = e_init(sa);
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc) e0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa.a1v[kc], rtop[kc], e0, 0, 0, 0);
+                const v4d e1 = run_strip(sa, e0, sb, true);
+                load_strip(2, sa);
+                __builtin_amdgcn_sched_barrier(0);
+                const v4d e2 = run_strip(sb, e1, sa, true);
+                load_strip(3, sb);
+                __builtin_amdgcn_sched_barrier(0);
+                const v4d e3 = run_strip(sa, e2, sb, true);
+                (void)run_strip(sb, e3, sb, false);
+                cacc += cacc1;
+#pragma unroll
+                for (int mt = 0; mt < NMT; ++mt) macc[mt] += macc1[mt];
+                // the next block's global loads go out only now: their 64 staging VGPRs are dead during
+                // phase A (that is what pays for the second strip register set) and the loads still have
+                // all of phase B to land
+                prefetch(s + 1 < nk ? blk + gridDim.x : blk);
                 double* __restrict__ mine = red + (size_t)wave * NV * 16;
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
@@ -313,7 +365,7 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                     double* __restrict__ upb = upbuf + (s & 1) * 16 * NU;
                     for (int pass0 = 0; pass0 < 16; pass0 += RPW) {
                         const int rloc = pass0 + rl;
-                        const bool ok = rl < RPW && rloc < nvalid;
+                        const bool ok = rl < RPW && rloc < 16;
                         const int rlc = rloc < 16 ? rloc : 15;
                         double cj = 0.0, Ms[NU];
 #pragma unroll
@@ -333,14 +385,30 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                         const int64_t gi = ok ? (row0 + rloc) * NU + j : 0;
                         double uu = pass0 == 0 ? uu0 : u[gi];
                         double up = pass0 == 0 ? up0 : u_prev[gi];
-                        double beta = n_iter2 > 0 ? beta_tab[0] : 0.0;
-                        for (int t2 = 0; t2 < n_iter2; ++t2) {
-                            const double beta_next = beta_tab[t2 + 1 < n_iter2 ? t2 + 1 : t2];
-                            const double ut = fma(beta, uu - up, uu);
-                            const double base = mode == 1 ? uu : ut;  // deconvolution.py:163 vs :88
-                            up = uu;
-                            uu = f_sub_clamp01(ut + cj, f_dot_tree<NU, 0, NU>(base, Ms, lane0));
-                            beta = beta_next;
+                        // The momentum coefficients ride in a VGPR (lane t holds beta_t) and reach the loop
+                        // through v_readlane: an LDS read here would sit on the dependent chain every step.
+                        for (int t0 = 0; t0 < n_iter2; t0 += 64) {
+                            const int tl = t0 + lane < n_iter2 ? t0 + lane : n_iter2 - 1;
+                            const double bvec = beta_tab[tl];
+                            const int b_lo = __double2loint(bvec), b_hi = __double2hiint(bvec);
+                            const int t_end = n_iter2 - t0 < 64 ? n_iter2 - t0 : 64;
+                            if (mode == 1) {  // deconvolution.py:163: gradient at the previous iterate
+                                for (int t2 = 0; t2 < t_end; ++t2) {
+                                    const double beta = __hiloint2double(__builtin_amdgcn_readlane(b_hi, t2),
+                                                                         __builtin_amdgcn_readlane(b_lo, t2));
+                                    const double ut = fma(beta, uu - up, uu);
+                                    up = uu;
+                                    uu = f_sub_clamp01(ut + cj, f_dot_tree<NU, 0, NU>(up, Ms, lane0));
+                                }
+                            } else {          // deconvolution.py:88: gradient at the extrapolated point
+                                for (int t2 = 0; t2 < t_end; ++t2) {
+                                    const double beta = __hiloint2double(__builtin_amdgcn_readlane(b_hi, t2),
+                                                                         __builtin_amdgcn_readlane(b_lo, t2));
+                                    const double ut = fma(beta, uu - up, uu);
+                                    up = uu;
+                                    uu = f_sub_clamp01(ut + cj, f_dot_tree<NU, 0, NU>(ut, Ms, lane0));
+                                }
+                            }
                         }
                         if (ok) {
                             // to LDS only: a C wave stores the rows to HBM next step, so that no A wave ever
@@ -372,19 +440,17 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
         for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
         const int sC = wcol0 + lane;  // lane = sample column
 
-        auto accum_rows = [&](int buf, int r_begin, int nvalid) {
+        auto accum_rows = [&](int buf, int r_begin, int n_rows) {
             const char* __restrict__ tile = tile_of(buf);
             const double* __restrict__ tileV = reinterpret_cast<const double*>(tile);
             const float* __restrict__ tileD = reinterpret_cast<const float*>(tile + kTileVBytes);
             const double* __restrict__ ub = ubuf + buf * 16 * NU;
             const double* __restrict__ rb = rtbuf + buf * 16 * NCTL;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
+            for (int rr = 0; rr < 8; ++rr) {
+                if (rr >= n_rows) break;
                 const int r = r_begin + rr;
-                // rows past the end of the matrix hold a copy of row N-1: their weight is zeroed (no branch,
-                // so that the LDS reads of the four rows can all be in flight)
-                const double dm = r < nvalid ? 1.0 : 0.0;
-                const double d = dm * (double)tileD[r * kTileRowFloats + lane];
+                const double d = (double)tileD[r * kTileRowFloats + lane];
                 const double v = tileV[r * kTileRowDoubles + lane];
                 double uj[NU], t[NU];
                 if constexpr ((NU & 1) == 0) {
@@ -422,23 +488,22 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
 
         DMF_STAMP_DECL
         for (int s = 0; s <= nk; ++s) {
-            int nvalid = 0, buf = 0;
+            int buf = 0;
             if (s >= 1) {
                 const int64_t row0 = (blockIdx.x + (int64_t)(s - 1) * gridDim.x) * 16;
-                nvalid = N - row0 < 16 ? (int)(N - row0) : 16;
                 buf = (s - 1) & 1;
                 if (cidx == 0) {  // the block's rows are contiguous in u: coalesced stores
-                    for (int e = lane; e < nvalid * NU; e += 64) {
+                    for (int e = lane; e < 16 * NU; e += 64) {
                         u[row0 * NU + e] = ubuf[buf * 16 * NU + e];
                         u_prev[row0 * NU + e] = upbuf[buf * 16 * NU + e];
                     }
                 }
-                accum_rows(buf, 8 * half, nvalid);
+                if (kCRowsBeforeX > 0) accum_rows(buf, 8 * half, kCRowsBeforeX);
             }
-            DMF_STAMP(0)  // first 4 rows
+            DMF_STAMP(0)  // rows before X
             __syncthreads();  // ---- barrier X
             DMF_STAMP(2)  // wait at X
-            if (s >= 1) accum_rows(buf, 8 * half + 4, nvalid);
+            if (s >= 1) accum_rows(buf, 8 * half + kCRowsBeforeX, 8 - kCRowsBeforeX);
             DMF_STAMP(1)  // last 4 rows
             __syncthreads();  // ---- barrier Y
             DMF_STAMP(4)  // wait at Y
@@ -512,7 +577,7 @@ bool rowpass_fused_supported(int S, int n_c, int n_u) {
 int rowpass_fused_grid(int64_t N, int S) {
     const int NW = (S + 63) / 64;
     const int per_cu = NW <= 2 ? 2 : 1;  // LDS: two tile buffers per column group
-    const int64_t nblk = (N + 15) / 16;
+    const int64_t nblk = N / 16;
     const int64_t g = 256 * per_cu;
     return (int)(nblk < g ? nblk : g);
 }
@@ -531,7 +596,7 @@ static hipError_t launch_fused_t(const double* V, const double* D, const double*
     } else {
         const int NW = (S + 63) / 64;
         const size_t lds = fused_lds_bytes(S, 4 * NKC, NU, n_iter2);
-        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        if (lds > 160 * 1024 || (N & 15) != 0 || N < 16) return hipErrorInvalidValue;
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)k_rowpass_fused<NKC, NU>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
