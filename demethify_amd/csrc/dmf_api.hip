@@ -291,9 +291,9 @@ int enqueue_alpha_phase(dmf_solver* s, int n_iter2) {
                                               (int)s->n_u, n_iter2, s->partials, ctx->stream));
         return DMF_OK;
     }
-    dmf::set_alpha_thread_per_sample(ctx->generic_level == 1 || ctx->generic_level == 2);
+    const bool thread_per_sample = ctx->generic_level == 1 || ctx->generic_level == 2;
     HIP_TRY(dmf::launch_alpha_phase(s->gb, s->alpha, s->alpha_prev, s->state, (int)p->S, (int)p->n_c,
-                                    (int)s->n_u, n_iter2, s->partials, ctx->stream));
+                                    (int)s->n_u, n_iter2, s->partials, thread_per_sample, ctx->stream));
     return DMF_OK;
 }
 

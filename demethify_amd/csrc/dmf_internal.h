@@ -108,11 +108,11 @@ hipError_t launch_u_step_direct(const double* V, const double* D, const double* 
 bool u_step_direct_supported(int S, int n_c, int n_u);
 
 // alpha phase on the packed Gram buffer gb[(K+1)(K+2)/2][S]
+// thread_per_sample selects the one-thread-per-sample kernels (test levels 1 and 2) instead of the
+// lane-parallel one (G lanes per sample); partials must hold 2 * (ceil(S / 64) + S) doubles
 hipError_t launch_alpha_phase(const double* gb, double* alpha, double* alpha_prev,
                               SolverState* state, int S, int n_c, int n_u, int n_iter2,
-                              double* partials, hipStream_t st);
-// partials must hold 2 * max(ceil(S / 64), ceil(S * 32 / 64)) doubles (lane-parallel kernel: G lanes per sample)
-void set_alpha_thread_per_sample(bool on);
+                              double* partials, bool thread_per_sample, hipStream_t st);
 hipError_t launch_set_lh(SolverState* state, hipStream_t st);
 // purity-constrained alpha phase (Frank-Wolfe, deconvolution.py:280-302) on the same packed Gram buffer
 hipError_t launch_alpha_frank_wolfe(const double* gb, double* alpha, const double* purity, SolverState* state,

@@ -10,11 +10,6 @@
 
 namespace dmf {
 
-// test hook: force the one-thread-per-sample alpha kernels (kernel selection levels 1 and 2)
-static bool g_alpha_thread_per_sample = false;
-void set_alpha_thread_per_sample(bool on) { g_alpha_thread_per_sample = on; }
-static bool alpha_thread_per_sample() { return g_alpha_thread_per_sample; }
-
 // Compile-time bitonic network, descending; every index is a constant after unrolling so the
 // array stays in registers.
 template <int KMAX>
@@ -418,9 +413,9 @@ static hipError_t launch_alpha_lanes_t(const double* gb, double* alpha, double* 
 
 hipError_t launch_alpha_phase(const double* gb, double* alpha, double* alpha_prev,
                               SolverState* state, int S, int n_c, int n_u, int n_iter2,
-                              double* partials, hipStream_t st) {
+                              double* partials, bool thread_per_sample, hipStream_t st) {
     const int K = n_c + n_u;
-    if (!alpha_thread_per_sample()) {
+    if (!thread_per_sample) {
         if (K <= 4) return launch_alpha_lanes_t<4>(gb, alpha, alpha_prev, state, S, K, n_u, n_iter2, partials, st);
         if (K <= 8) return launch_alpha_lanes_t<8>(gb, alpha, alpha_prev, state, S, K, n_u, n_iter2, partials, st);
         if (K <= 16) return launch_alpha_lanes_t<16>(gb, alpha, alpha_prev, state, S, K, n_u, n_iter2, partials, st);

@@ -177,7 +177,11 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
         // LDS rows / columns this lane reads to form the MFMA A operands of a strip
         const int e_col = wcol0 + 4 * (m16 & 3) + (m16 >> 2);   // + 16 t : first product, m <-> sample
         const int k_col = wcol0 + 4 * q;                         // + 16 t + r : k-step r, k = q <-> sample
-        const int a2_row = m16 < NU ? NCT + m16 : ZROW;
+        // c = a_unk (D*E)^T: with at most 4 unknown types the 4x4x4 (4 blocks) MFMA does it with every lane
+        // useful (blocks = groups of 4 rows; A[b][i][k] sits at lane 16 k + 4 b + i, D[b][i][j] at lane
+        // 16 i + 4 b + j, verified in tools/mfma_probe.hip): 18 cycles instead of 64 per k-step.
+        constexpr bool kSmallC = NU <= 4;
+        const int a2_row = kSmallC ? ((m16 & 3) < NU ? NCT + (m16 & 3) : ZROW) : (m16 < NU ? NCT + m16 : ZROW);
         int jp_row[NMT], lp_row[NMT];
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
@@ -285,6 +289,7 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                 // Two accumulator sets (even / odd k-steps): a dependent FP64 MFMA issued right behind its
                 // producer stalls for most of the producer's latency, four-plus independent chains do not.
                 v4d cacc = {0.0, 0.0, 0.0, 0.0}, cacc1 = cacc;
+                double csm0 = 0.0, csm1 = 0.0;  // kSmallC: c[unknown q][row m16], one double per lane
                 v4d macc[NMT], macc1[NMT];
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt) macc[mt] = macc1[mt] = cacc;
@@ -299,8 +304,13 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                     v4d en = e_init(Rn);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (r & 1) cacc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2v[r], w[r], cacc1, 0, 0, 0);
-                        else cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2v[r], w[r], cacc, 0, 0, 0);
+                        if constexpr (kSmallC) {
+                            if (r & 1) csm1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2v[r], w[r], csm1, 0, 0, 0);
+                            else csm0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2v[r], w[r], csm0, 0, 0, 0);
+                        } else {
+                            if (r & 1) cacc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2v[r], w[r], cacc1, 0, 0, 0);
+                            else cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2v[r], w[r], cacc, 0, 0, 0);
+                        }
 #pragma unroll
                         for (int mt = 0; mt < NMT; ++mt) {
                             const double pj = r == 0 ? R.jlo[mt].x : r == 1 ? R.jlo[mt].y : r == 2 ? R.jhi[mt].x : R.jhi[mt].y;
@@ -333,6 +343,7 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                 const v4d e3 = run_strip(sa, e2, sb, true);
                 (void)run_strip(sb, e3, sb, false);
                 cacc += cacc1;
+                if constexpr (kSmallC) cacc[0] = csm0 + csm1;  // same place as register 0 of the 16x16 tile
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt) macc[mt] += macc1[mt];
                 // the next block's global loads go out only now: their 64 staging VGPRs are dead during
