@@ -78,8 +78,10 @@ def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, 
                     u, alpha = solve_problem(resampled, u0, a0, L.DMF_MODE_PARTIAL, n_iter1, n_iter2, tol,
                                              purity=purity_frac)
                 local.append((i, (u, alpha)))
-    merged = shard.gather_objects(local)
-    props_stack = np.stack([pa for _, (_, pa) in merged])  # (B, K, S)
+    # proportions (K x S per replicate) go to every rank; the profile stacks (N x n_u per replicate) only to
+    # rank 0, which computes their percentiles and writes both CSVs
+    merged = shard.gather_objects([(i, pa) for i, (_, pa) in local])
+    props_stack = np.stack([pa for _, pa in merged])  # (B, K, S)
 
     results = []
     lower_p = np.percentile(props_stack, lower_percentile, axis=0)
@@ -96,12 +98,13 @@ def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, 
     results.append(proportions_df)
 
     if not supervised:
-        u_stack = np.stack([pu for _, (pu, _) in merged])  # (B, N, n_u), by resampled position as upstream
-        lower_u = np.percentile(u_stack, lower_percentile, axis=0)
-        upper_u = np.percentile(u_stack, upper_percentile, axis=0)
-        ref_estimate_df = pd.DataFrame({unknown_header[k]: [(lower_u[j, k], upper_u[j, k]) for j in range(n_rows)]
-                                        for k in range(n_u)})
-        if rank == 0:
+        merged_u = shard.gather_objects([(i, pu) for i, (pu, _) in local], root_only=True)
+        if merged_u is not None:
+            u_stack = np.stack([pu for _, pu in merged_u])  # (B, N, n_u), by resampled position as upstream
+            lower_u = np.percentile(u_stack, lower_percentile, axis=0)
+            upper_u = np.percentile(u_stack, upper_percentile, axis=0)
+            ref_estimate_df = pd.DataFrame({unknown_header[k]: [(lower_u[j, k], upper_u[j, k]) for j in range(n_rows)]
+                                            for k in range(n_u)})
             ref_estimate_df.to_csv(outdir + "/confidence_interval_methylation_estimate.csv", index=False)
-        results.append(ref_estimate_df)
+            results.append(ref_estimate_df)
     return results

@@ -87,11 +87,13 @@ def _init_distributed():
     import torch
     import torch.distributed as dist
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = int(os.environ.get("DEMETHIFY_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    backend = os.environ.get("DEMETHIFY_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:  # CPU rehearsal of the host logic
+        torch.cuda.set_device(device)
+    if backend == "nccl":  # RCCL over xGMI: one rank per GPU
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+    else:  # gloo: CPU collectives (tests; several ranks may then share one GPU via DEMETHIFY_DEVICE)
         dist.init_process_group(backend="gloo")
     return dist.get_rank()
 

@@ -92,7 +92,8 @@ class Context:
 def get_context(device: int | None = None) -> Context:
     """Process-wide context cache; default device = LOCAL_RANK (one process per GPU) or 0."""
     if device is None:
-        device = int(os.environ.get("LOCAL_RANK", "0"))
+        # DEMETHIFY_DEVICE overrides the one-process-per-GPU default (rehearsing N ranks on one GPU)
+        device = int(os.environ.get("DEMETHIFY_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     ctx = _contexts.get(device)
     if ctx is None:
         ctx = _contexts[device] = Context(device)

@@ -80,16 +80,23 @@ def broadcast_arrays(arrays, src: int):
     return tuple(out)
 
 
-def gather_objects(local):
-    """All-gather of small picklable per-rank results (lists of (k, payload)); returns the merged,
-    k-sorted list on every rank."""
+def gather_objects(local, root_only=False):
+    """Gather of picklable per-rank results (lists of (k, payload)); returns the merged, k-sorted list on
+    every rank, or with ``root_only`` on rank 0 alone (None elsewhere): the bootstrap's profile stacks are
+    n_bootstrap x N x n_u doubles, which only the rank that writes the CSV needs."""
     rank, world, dev = dist_state()
     if world == 1:
         return sorted(local, key=lambda kv: kv[0])
     import torch.distributed as dist
 
-    bucket = [None] * world
-    dist.all_gather_object(bucket, local)
+    if root_only:
+        bucket = [None] * world if rank == 0 else None
+        dist.gather_object(local, bucket, dst=0)
+        if rank != 0:
+            return None
+    else:
+        bucket = [None] * world
+        dist.all_gather_object(bucket, local)
     merged = [kv for part in bucket for kv in part]
     return sorted(merged, key=lambda kv: kv[0])
 

@@ -149,3 +149,39 @@ def test_confidence_intervals_match_oracle_bootstrap(tmp_path, toy):
     prof = pd.read_csv(tmp_path / "confidence_interval_methylation_estimate.csv")
     a, b = eval(prof["unknown_cell_1"][17], {"np": np})
     assert abs(a - lo_u[17, 0]) < 1e-8 and abs(b - hi_u[17, 0]) < 1e-8
+
+
+def run_cli_ranks(n_ranks, *argv):
+    """Two ranks sharing cuda:0 with gloo collectives: the sharded drivers on the real kernels."""
+    import os
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, DEMETHIFY_DIST_BACKEND="gloo", DEMETHIFY_DEVICE="0")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "demethify_amd", *argv],
+                          cwd=ROOT, capture_output=True, text=True, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_two_ranks_give_the_single_process_answer(tmp_path):
+    """--restart, --confidence and --ic sharded over 2 ranks == the same command on 1 rank."""
+    base = ["--ref", REF, "--methfreq", *SAMPLES, "--bedmethyl", "--noprint", "--iterations", "30", "20"]
+    cases = {"restart": ["--nbunknown", "1", "--restart", "5"],
+             "ci": ["--nbunknown", "1", "--confidence", "90", "5"]}
+    for name, extra in cases.items():
+        run_cli(*base, *extra, "--outdir", str(tmp_path / f"{name}_1"))
+        run_cli_ranks(2, *base, *extra, "--outdir", str(tmp_path / f"{name}_2"))
+        files = ["celltypes_proportions.csv", "methylation_profile_estimate.csv"]
+        if name == "ci":
+            files += ["confidence_interval_celltypes_proportions.csv", "confidence_interval_methylation_estimate.csv"]
+        for f in files:
+            assert (tmp_path / f"{name}_1" / f).read_text() == (tmp_path / f"{name}_2" / f).read_text(), (name, f)
+    # model selection: 25 candidates dealt to 2 ranks (default iterations: the committed folder is the target)
+    run_cli_ranks(2, "--ref", REF, "--methfreq", *SAMPLES, "--bedmethyl", "--noprint", "--ic", "AIC", "--outdir",
+                  str(tmp_path / "ic_2"))
+    assert (tmp_path / "ic_2" / "log.log").read_text().strip().endswith("Number of unknowns that minimises AIC : 10")
+    same_csv(tmp_path / "ic_2" / "celltypes_proportions.csv", UPSTREAM / "model_selection" / "celltypes_proportions.csv", 1e-7)

@@ -57,6 +57,8 @@ def _worker(rank, world, port, out_dir):
     # 3. object gather keeps item order
     merged = shard.gather_objects([(k, k * k) for k in shard.my_items(7)])
     assert merged == [(k, k * k) for k in range(7)]
+    rooted = shard.gather_objects([(k, -k) for k in shard.my_items(5)], root_only=True)
+    assert (rooted == [(k, -k) for k in range(5)]) if rank == 0 else rooted is None
     # 4. broadcast from a non-zero owner
     payload = (np.full((3, 2), 5.0),) if rank == 1 else (np.empty((3, 2)),)
     (got,) = shard.broadcast_arrays(payload, 1)
