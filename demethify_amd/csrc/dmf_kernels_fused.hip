@@ -4,13 +4,14 @@
 //   load    coalesced global loads (16 B per lane, two rows per instruction) -> registers -> LDS tile
 //   phase A read the tile in the row-on-lane layout and run the three FP64-MFMA contractions of
 //           dmf_kernels_rowpass_mfma.hip (E = V - Rt a_known, c = a_unk (D*E)^T, M = P D^T)
-//   phase B n_iter2 row-local accelerated projected-gradient steps (one wave, round robin); the new u
-//           rows go to global memory and to LDS
+//   phase B n_iter2 row-local accelerated projected-gradient steps (one wave, round robin); the new u / u_
+//           rows go to LDS (a wave of the other team stores them to HBM one step later)
 //   phase C read the tile sample-on-lane and accumulate, in registers across all row blocks, the
 //           u-dependent entries of the per-sample Gram matrices for the alpha phase
 //           (cross[k][j] += d Rt_k u_j, uu[j<=l] += d u_j u_l, bu[j] += d v u_j), as dmf_kernels_gram.hip
-// Phases A/B and phase C run on two wave teams of the same workgroup, one block apart, so that each SIMD
-// always has an MFMA-bound wave and a VALU-bound wave resident (see the kernel's comment).
+// Phases A/B and phase C run on two wave teams of the same workgroup, one block apart (see the kernel's
+// comment): FP64 MFMA and FP64 VALU share one pipe on gfx950, so the point of the split is not co-issue but
+// keeping that pipe fed while the other team waits on LDS, a barrier or phase B's dependent chain.
 // At the end every workgroup stores its accumulators as one slab (job order of the solver's table) and
 // its share of ||u||_F^2; k_gram_reduce sums the slabs in fixed order.
 //
@@ -96,12 +97,13 @@ __device__ __forceinline__ double f_sub_clamp01(double a, double b) {
 // Team layout: a workgroup has 3 NW waves (NW = ceil(S / 64) column groups of 64 samples).
 //   A team  waves [0, NW): A wave w owns column group w for phase A (MFMA) and takes turns at phase B
 //   C team  waves [NW, 3 NW): C wave (g, h) owns column group g and rows [8h, 8h + 8) of every block
-// so each SIMD holds one MFMA-bound wave and two VALU-bound waves (a lone wave issues FP64 VALU at half
-// rate).  Step s overlaps the A team's work on block s with the C team's work on block s - 1:
-//   A team  store the prefetched V / D tile of block s into LDS buffer s & 1, issue the global loads of
-//           block s + 1 into registers, phase A -> partial c / M in LDS
-//           -- barrier X --   phase B (one A wave, round robin) -> u rows to global + LDS   -- barrier Y --
-//   C team  phase C, first 4 of its rows of block s - 1   -- X --   last 4 rows   -- Y --
+// so each SIMD holds one MFMA-bound wave and two VALU-bound waves (a lone wave issues FP64 VALU at about
+// two thirds of the rate two waves reach).  Step s overlaps the A team's work on block s with the C team's work on block s - 1:
+//   A team  store the prefetched V / D tile of block s into LDS buffer s & 1, phase A -> partial c / M in
+//           LDS, then issue the global loads of block s + 1 into registers
+//           -- barrier X --   phase B (one A wave, round robin) -> u / u_ rows to LDS   -- barrier Y --
+//   C team  store block s - 1's u / u_ rows to HBM, phase C on the first 4 of its rows of block s - 1
+//           -- X --   last 4 rows   -- Y --
 // The alpha-derived MFMA A operands are re-read from an LDS copy of alpha for every strip (cheap) instead
 // of living in ~90 VGPRs, which is what lets three waves per SIMD fit.
 template <int NKC, int NU>
