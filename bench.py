@@ -70,9 +70,11 @@ def cpu_baseline(V_host, D_host, Rt_host, n_u, N_full, budget_iters=2):
     try:
         from threadpoolctl import threadpool_info
 
-        blas = [f"{i.get('internal_api')}:{i.get('num_threads')}" for i in threadpool_info()]
+        pools = threadpool_info()
+        blas = [f"{i.get('internal_api')}:{i.get('num_threads')}" for i in pools]
+        blas_threads = max([int(i.get("num_threads") or 1) for i in pools if i.get("user_api") == "blas"] or [1])
     except Exception:  # pragma: no cover
-        blas = []
+        blas, blas_threads = [], 1
     u0, R, a0 = osol.init_partial("uniform_", V_host, D_host, Rt_host, n_u, seed=1)
     t0 = time.perf_counter()
     osol.solve_partial(u0, R, a0, V_host, D_host, Rt_host, n_u, budget_iters, 20, 0.0,
@@ -83,7 +85,10 @@ def cpu_baseline(V_host, D_host, Rt_host, n_u, N_full, budget_iters=2):
     return {
         "value": rate_sample * n_s / N_full,
         "unit": "outer iters/s",
-        "cores": os.cpu_count(),
+        # threads actually used: numpy's elementwise temporaries are single-threaded, only the skinny dgemms
+        # fan out over the BLAS pool (default threading, as the reference would run)
+        "cores": blas_threads,
+        "host_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"{budget_iters} outer iterations (T2=20) of oracle/solver.py on the first {n_s} of {N_full} "
                   f"CpG rows x {V_host.shape[1]} samples, {dt:.1f} s wall; rate scaled by {n_s}/{N_full}",
