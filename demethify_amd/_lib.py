@@ -74,6 +74,18 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m demethify_amd._build` "
             "(there is no CPU fallback)")
+    # If PyTorch-ROCm lives in this process (bench.py, the multi-GPU drivers), let it bring up its HIP
+    # runtime first: torch's wheel bundles its own libamdhip64, and initialising ours before it leaves torch
+    # without a device ("no ROCm-capable device is detected").
+    import sys
+
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:  # pragma: no cover - torch without a usable GPU: our own checks will report it
+            pass
     lib = C.CDLL(str(LIB_PATH))
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -50,6 +50,19 @@ def read_profile(folder):
     return pd.read_csv(UPSTREAM / folder / "methylation_profile_estimate.csv").values
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_runtime_first():
+    """Some GPU tests use torch tensors as device buffers: torch has to initialise its HIP runtime before the
+    library loads its own (see demethify_amd/_lib.py), so the order is settled once per session."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def ctx():
     """One device context for the whole GPU session."""

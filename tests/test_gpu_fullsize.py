@@ -1,0 +1,72 @@
+"""BASELINE.json sizes: config 2 against the oracle directly, the headline size through properties that do
+not depend on the size (the oracle would need minutes per iteration there)."""
+import numpy as np
+import pytest
+
+from oracle import solver as osol
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config2_full_size_against_oracle(ctx):
+    """BASELINE.json configs[1]: 1e5 CpG x 64 samples, 6 known + 2 unknown types, two outer iterations."""
+    from demethify_amd import _lib as L
+    from demethify_amd.deconvolution import solve_problem
+    from demethify_amd.device import Problem
+
+    V, D, Rt = osol.synthetic_problem(100_000, 64, 6, 2, seed=0, depth=50)
+    u0, R, a0 = osol.init_partial("uniform_", V, D, Rt, 2, seed=1)
+    wu, wa = osol.solve_partial(u0.copy(), R, a0.copy(), V, D, Rt, 2, 2, 20, 0.0,
+                                project=osol.simplex_project_columns_fast)
+    with Problem(ctx, V, D, Rt) as p:
+        gu, ga, cost, iters = solve_problem(p, u0, a0, L.DMF_MODE_PARTIAL, 2, 20, 0.0, return_info=True)
+        direct = p.cost(gu, ga)
+    assert iters == 2
+    assert rel_err(ga, wa) < 1e-9 and np.abs(gu - wu).max() < 1e-9
+    want = osol.weighted_cost(V, np.c_[Rt, wu], wa, D)
+    assert cost == pytest.approx(want, rel=1e-10) and direct == pytest.approx(want, rel=1e-12)
+
+
+def test_headline_size_properties(ctx):
+    """1e6 x 256, 12 + 4 (the bench workload): invariants of the iteration instead of an oracle run."""
+    torch = pytest.importorskip("torch")
+    from bench import make_inputs_on_device
+    from demethify_amd import _lib as L
+    from demethify_amd.device import Problem, Solver
+
+    N, S, n_c, n_u = 1_000_000, 256, 12, 4
+    V, D, Rt = make_inputs_on_device(torch, torch.device("cuda", 0), N, S, n_c, n_u, seed=0)
+    rs = np.random.RandomState(1)
+    u0 = rs.uniform(size=(N, n_u))
+    a0 = rs.dirichlet(np.ones(n_c + n_u), S).T
+    with Problem(ctx, V, D, Rt) as p:
+        costs = []
+        with Solver(p, u0, a0, L.DMF_MODE_PARTIAL) as s:
+            _, _, c0, _ = s.get()
+            costs.append(c0)
+            for _ in range(3):
+                s.step(1, 20, 0.0)
+                costs.append(s.get_cost()[0])
+            u1, a1, c1, it1 = s.get()
+        # the cost the stop test uses (Gram form) equals the streaming cost of the same iterate
+        assert p.cost(u1, a1) == pytest.approx(c1, rel=1e-9)
+        assert it1 == 3 and all(b < a for a, b in zip(costs, costs[1:]))  # monotone decrease from a random start
+        # feasibility: proportions on the simplex, profiles in [0, 1]
+        assert np.abs(a1.sum(axis=0) - 1).max() < 1e-12 and a1.min() >= 0
+        assert u1.min() >= 0 and u1.max() <= 1
+        # fixed summation orders everywhere: a second run is bitwise identical
+        with Solver(p, u0, a0, L.DMF_MODE_PARTIAL) as s:
+            s.step(3, 20, 0.0)
+            u2, a2, c2, _ = s.get()
+        assert np.array_equal(u1, u2) and np.array_equal(a1, a2) and c1 == c2
+        # the unfused kernels (a different summation order) land on the same iterate
+        ctx.set_generic(3)
+        try:
+            with Solver(p, u0, a0, L.DMF_MODE_PARTIAL) as s:
+                s.step(3, 20, 0.0)
+                u3, a3, c3, _ = s.get()
+        finally:
+            ctx.set_generic(0)
+        assert np.abs(a3 - a1).max() < 1e-9 and np.abs(u3 - u1).max() < 1e-9 and c3 == pytest.approx(c1, rel=1e-10)
