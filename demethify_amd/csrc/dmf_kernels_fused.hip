@@ -610,10 +610,15 @@ static hipError_t launch_fused_t(const double* V, const double* D, const double*
         const int NW = (S + 63) / 64;
         const size_t lds = fused_lds_bytes(S, 4 * NKC, NU, n_iter2);
         if (lds > 160 * 1024 || (N & 15) != 0 || N < 16) return hipErrorInvalidValue;
-        if (lds > 48 * 1024) {
+        // raise the dynamic-LDS limit once per (instantiation, device): this launch sits in the per-iteration loop
+        static bool lds_limit_raised[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (lds > 48 * 1024 && !lds_limit_raised[dev]) {
             hipError_t e = hipFuncSetAttribute((const void*)k_rowpass_fused<NKC, NU>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
+            lds_limit_raised[dev] = true;
         }
         const int grid = rowpass_fused_grid(N, S);
         *grid_out = grid;
