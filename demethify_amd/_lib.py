@@ -42,6 +42,7 @@ SIGNATURES = {
     "dmf_project_simplex": (C.c_int, [_p, _p, _i64, _i64, C.c_double, C.c_int, _p]),
     "dmf_update_u": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, C.c_int, C.c_int, _dbl_p, _p, _p]),
     "dmf_update_alpha": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, C.c_int, _dbl_p, _p, _p]),
+    "dmf_percentile_axis0": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, C.c_int, _p]),
     "dmf_solver_create": (C.c_int, [_p, _p, _p, _p, _i64, C.c_int, C.c_int, C.POINTER(_p)]),
     "dmf_solver_set_purity": (C.c_int, [_p, _p, C.c_int]),
     "dmf_solver_step": (C.c_int, [_p, _i64, _i64, C.c_double, C.POINTER(_i64), C.POINTER(C.c_int)]),

@@ -3,9 +3,10 @@
 Replicate i resamples the CpG rows with replacement (``sklearn.utils.resample(..., random_state=seed_i)``
 upstream, i.e. ``RandomState(seed_i).randint(0, N, N)`` applied to meth_f, counts and ref alike), runs a
 full solve on the resampled problem and contributes one column per sample / unknown to the percentile
-bounds.  The full data set is uploaded once; each replicate is a row gather on the device.  With
-torch.distributed initialised, replicate i runs on rank i mod world and the per-replicate factors are
-gathered.
+bounds.  The full data set is uploaded once; each replicate is a row gather on the device; the percentiles
+over the replicates are taken on the device too (dmf_percentile_axis0).  With torch.distributed initialised,
+replicate i runs on rank i mod world, the KB-sized proportions are gathered and the profile stacks are
+re-partitioned by CpG range with one all-to-all.
 """
 from __future__ import annotations
 
@@ -78,14 +79,17 @@ def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, 
                     u, alpha = solve_problem(resampled, u0, a0, L.DMF_MODE_PARTIAL, n_iter1, n_iter2, tol,
                                              purity=purity_frac)
                 local.append((i, (u, alpha)))
-    # proportions (K x S per replicate) go to every rank; the profile stacks (N x n_u per replicate) only to
-    # rank 0, which computes their percentiles and writes both CSVs
+    # proportions (K x S per replicate, KB-sized) go to every rank
     merged = shard.gather_objects([(i, pa) for i, (_, pa) in local])
     props_stack = np.stack([pa for _, pa in merged])  # (B, K, S)
+    q = [lower_percentile, upper_percentile]
 
     results = []
-    lower_p = np.percentile(props_stack, lower_percentile, axis=0)
-    upper_p = np.percentile(props_stack, upper_percentile, axis=0)
+    if supervised:
+        # (no device in play on this branch: NNLS per sample on the host, as upstream)
+        lower_p, upper_p = np.percentile(props_stack, q, axis=0)
+    else:
+        lower_p, upper_p = get_context().percentile_axis0(props_stack, q)
     unknown_header = [] if supervised else ["unknown_cell_" + str(i + 1) for i in range(n_u)]
     cell_types = header + unknown_header
     table = {f"Sample_{i + 1}": [(lower_p[k, i], upper_p[k, i]) for k in range(n_ct + n_u)]
@@ -98,11 +102,14 @@ def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, 
     results.append(proportions_df)
 
     if not supervised:
-        merged_u = shard.gather_objects([(i, pu) for i, (pu, _) in local], root_only=True)
-        if merged_u is not None:
-            u_stack = np.stack([pu for _, pu in merged_u])  # (B, N, n_u), by resampled position as upstream
-            lower_u = np.percentile(u_stack, lower_percentile, axis=0)
-            upper_u = np.percentile(u_stack, upper_percentile, axis=0)
+        # Profile estimates: B x N x n_u doubles (16 GB at 500 x 1e6 x 4).  Each rank holds the replicates it
+        # ran; one all-to-all re-partitions them by CpG range and every rank takes the percentiles of its
+        # range on its GPU (shard.percentile_over_replicates); rank 0 writes the CSV.
+        local_u = (np.stack([pu.reshape(-1) for _, (pu, _) in local]) if local
+                   else np.empty((0, n_rows * n_u)))
+        bounds = shard.percentile_over_replicates(local_u, n_bootstrap, q, get_context().percentile_axis0)
+        if bounds is not None:
+            lower_u, upper_u = (b.reshape(n_rows, n_u) for b in bounds)  # by resampled position, as upstream
             ref_estimate_df = pd.DataFrame({unknown_header[k]: [(lower_u[j, k], upper_u[j, k]) for j in range(n_rows)]
                                             for k in range(n_u)})
             ref_estimate_df.to_csv(outdir + "/confidence_interval_methylation_estimate.csv", index=False)

@@ -810,6 +810,60 @@ int dmf_project_simplex(dmf_context* ctx, const double* X, int64_t K, int64_t S,
     return st;
 }
 
+// numpy's "linear" percentile (numpy/lib/_function_base_impl.py: _quantile, _get_indexes, _get_gamma):
+// virtual index (n - 1) * (q / 100), its floor and the next index, gamma = the fractional part
+static dmf::PercentilePlan percentile_plan(int64_t n, double q_percent) {
+#pragma clang fp contract(off)  // numpy rounds the product before subtracting the floor
+    dmf::PercentilePlan pl{};
+    const double quantile = q_percent / 100.0;
+    const double vi = (double)(n - 1) * quantile;
+    if (vi >= (double)(n - 1)) {
+        pl.k_prev = pl.k_next = n - 1;
+        pl.gamma = 0.0;
+    } else if (vi < 0.0) {
+        pl.k_prev = pl.k_next = 0;
+        pl.gamma = 0.0;
+    } else {
+        const double fl = std::floor(vi);
+        pl.k_prev = (long long)fl;
+        pl.k_next = pl.k_prev + 1;
+        pl.gamma = vi - fl;
+    }
+    return pl;
+}
+
+int dmf_percentile_axis0(dmf_context* ctx, const double* x, int64_t n, int64_t m, const double* q, int64_t n_q,
+                         int flags, double* out) {
+    DMF_TRY(check_ctx(ctx));
+    if (x == nullptr || q == nullptr || out == nullptr || n < 1 || m < 1 || n_q < 1) return DMF_ERR_BAD_ARG;
+    for (int64_t i = 0; i < n_q; ++i)
+        if (!(q[i] >= 0.0 && q[i] <= 100.0)) return DMF_ERR_BAD_ARG;  // numpy: "Percentiles must be in the range [0, 100]"
+    if (n > dmf::percentile_max_replicates()) return DMF_ERR_UNSUPPORTED;
+    const size_t in_bytes = (size_t)n * m * sizeof(double), out_bytes = (size_t)n_q * m * sizeof(double);
+    double *dx = nullptr, *dout = nullptr;
+    bool own_x = false;
+    int st = import_array(ctx, x, in_bytes, flags, (void**)&dx, &own_x);
+    if (st == DMF_OK) {
+        hipError_t e = hipSuccess;
+        if (flags & DMF_PTR_DEVICE) dout = out;
+        else e = hipMalloc((void**)&dout, out_bytes);
+        for (int64_t i = 0; i < n_q && e == hipSuccess; i += 2) {
+            const dmf::PercentilePlan p0 = percentile_plan(n, q[i]);
+            const bool two = i + 1 < n_q;
+            const dmf::PercentilePlan p1 = two ? percentile_plan(n, q[i + 1]) : p0;
+            e = dmf::launch_percentile_pair(dx, n, m, p0, p1, dout + i * m, two ? dout + (i + 1) * m : nullptr,
+                                            ctx->stream);
+        }
+        if (e == hipSuccess && !(flags & DMF_PTR_DEVICE))
+            e = hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) st = hip_fail(e, "percentile_axis0", __LINE__);
+        if (!(flags & DMF_PTR_DEVICE)) hipFree(dout);
+    }
+    if (own_x) hipFree(dx);
+    return st;
+}
+
 int dmf_update_u(dmf_context* ctx, const dmf_problem* p, const double* u, const double* u_prev,
                  const double* alpha, int64_t n_u, int64_t n_iter2, int mode, int flags,
                  double* scalars_io, double* out_u, double* out_u_prev) {

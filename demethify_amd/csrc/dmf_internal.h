@@ -40,6 +40,14 @@ struct GramJobTable {              // device arrays, one entry per accumulator
     int count;
 };
 
+// One percentile of numpy's "linear" method over n sorted values: lerp(sorted[k_prev], sorted[k_next], gamma)
+struct PercentilePlan {
+    long long k_prev, k_next;
+    double gamma;
+    int from_top;  // set by the launcher: which register tail of k_percentile_tails holds the two values
+    int pad;
+};
+
 // ---- launch wrappers (dmf_kernels_*.hip) ---------------------------------------------------
 // All wrappers enqueue on `st` and return the hipGetLastError() of their launches.
 
@@ -123,5 +131,10 @@ hipError_t launch_scatter_known_block(const double* gb_known, double* gb, int n_
                                       hipStream_t st);
 hipError_t launch_init_state(SolverState* state, const double* consts, const double* alpha,
                              int S, int n_c, int n_u, hipStream_t st);
+
+// two percentiles over axis 0 of x[n][m] -> out0[m], out1[m] (out1 may be null); dmf_kernels_percentile.hip
+hipError_t launch_percentile_pair(const double* x, int64_t n, int64_t m, PercentilePlan p0, PercentilePlan p1,
+                                  double* out0, double* out1, hipStream_t st);
+int64_t percentile_max_replicates();
 
 }  // namespace dmf

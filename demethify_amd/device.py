@@ -89,6 +89,34 @@ class Context:
                 "dmf_project_simplex")
         return out
 
+    def percentile_axis0(self, x, q):
+        """``np.percentile(x, q, axis=0)`` (numpy's default "linear" method, bootstrap.py:51-54 / :75-78) on
+        the device.  ``x``: (n replicates, ...) float64, a host array or a CUDA torch tensor; ``q``: a sequence
+        of percentiles.  Returns an array / tensor of shape (len(q),) + x.shape[1:] of the same kind as ``x``."""
+        qs = np.ascontiguousarray(np.atleast_1d(q), dtype=np.float64)
+        if _is_torch(x) and x.is_cuda:
+            import torch
+
+            if x.dtype != torch.float64:
+                raise TypeError("percentile_axis0 takes float64 data")
+            x = x.contiguous()
+            n, tail = x.shape[0], tuple(x.shape[1:])
+            m = int(np.prod(tail, dtype=np.int64))
+            out = torch.empty((len(qs),) + tail, dtype=torch.float64, device=x.device)
+            torch.cuda.current_stream(x.device).synchronize()  # x was produced on torch's stream, not ours
+            L.check(self._lib.dmf_percentile_axis0(self._h, _ptr(x), n, m, _ptr(qs), len(qs), L.DMF_PTR_DEVICE,
+                                                   _ptr(out)), "dmf_percentile_axis0")
+            return out
+        if _is_torch(x):
+            x = x.numpy()
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n, tail = x.shape[0], tuple(x.shape[1:])
+        m = int(np.prod(tail, dtype=np.int64))
+        out = np.empty((len(qs),) + tail, dtype=np.float64)
+        L.check(self._lib.dmf_percentile_axis0(self._h, _ptr(x), n, m, _ptr(qs), len(qs), 0, _ptr(out)),
+                "dmf_percentile_axis0")
+        return out
+
 
 def get_context(device: int | None = None) -> Context:
     """Process-wide context cache; default device = LOCAL_RANK (one process per GPU) or 0."""

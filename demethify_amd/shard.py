@@ -2,9 +2,11 @@
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the
 CPU tests).  The units (random restarts, bootstrap resamples, model-selection candidates) are
-independent, so work item k simply goes to rank k mod world and the only exchanges are KB-sized:
-one all-reduce(min) over the cost vector to pick the winning restart, and gathers of the
-per-item results.  No collective touches the N x S data path.
+independent, so work item k simply goes to rank k mod world and the exchanges on the solve path are
+KB-sized: one all-reduce(min) over the cost vector to pick the winning restart, and gathers of the
+per-item results.  No collective touches the N x S data path.  The one sizeable exchange is in the
+bootstrap's post-processing: the per-replicate profile estimates are re-partitioned from "by replicate"
+to "by CpG range" with one all-to-all, so that every rank can take the percentiles of its own range.
 """
 from __future__ import annotations
 
@@ -99,6 +101,51 @@ def gather_objects(local, root_only=False):
         dist.all_gather_object(bucket, local)
     merged = [kv for part in bucket for kv in part]
     return sorted(merged, key=lambda kv: kv[0])
+
+
+def split_positions(m, world):
+    """Contiguous, near-equal ranges of m positions, one per rank: [(begin, end)] * world."""
+    base, extra = divmod(m, world)
+    out, a = [], 0
+    for r in range(world):
+        b = a + base + (1 if r < extra else 0)
+        out.append((a, b))
+        a = b
+    return out
+
+
+def percentile_over_replicates(local_stack, n_items, q, percentile_fn):
+    """Percentiles over ALL replicates of a stack that is sharded by replicate (bootstrap.py:75-78).
+
+    ``local_stack``: (n_local, m) float64 array, the rows of the replicates this rank ran (rank r owns
+    replicates r, r + world, ... of ``n_items``); ``percentile_fn(x, q)`` -> (len(q), m') takes the percentiles
+    over axis 0 of a (n, m') array or tensor (the HIP kernel in the product, numpy in the CPU tests).
+    One all-to-all turns the "by replicate" partition into a "by position range" one (rank r receives the
+    columns of range r from every rank: n_items x m_r values), each rank reduces its range, and rank 0
+    collects the (len(q), m) result (None elsewhere)."""
+    rank, world, dev = dist_state()
+    if world == 1:
+        return np.asarray(percentile_fn(np.ascontiguousarray(local_stack), q))
+    import torch
+    import torch.distributed as dist
+
+    local = torch.as_tensor(np.ascontiguousarray(local_stack, dtype=np.float64)).to(dev)
+    n_local, m = local.shape
+    counts = [len(my_items(n_items, r, world)) for r in range(world)]
+    assert counts[rank] == n_local, (counts, rank, n_local)
+    ranges = split_positions(m, world)
+    send = torch.cat([local[:, a:b].reshape(-1) for a, b in ranges])
+    a, b = ranges[rank]
+    recv = torch.empty(n_items * (b - a), dtype=torch.float64, device=dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=[c * (b - a) for c in counts],
+                           input_split_sizes=[n_local * (hi - lo) for lo, hi in ranges])
+    del send, local
+    mine = percentile_fn(recv.view(n_items, b - a), q) if b > a else np.empty((len(np.atleast_1d(q)), 0))
+    mine = mine.cpu().numpy() if hasattr(mine, "cpu") else np.asarray(mine)
+    parts = gather_objects([(rank, mine)], root_only=True)
+    if parts is None:
+        return None
+    return np.concatenate([part for _, part in parts], axis=1)
 
 
 def restart_seed(seed, k):

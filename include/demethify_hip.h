@@ -118,6 +118,13 @@ int dmf_update_alpha(dmf_context* ctx, const dmf_problem* p, const double* u, in
                      const double* alpha, const double* alpha_prev, int64_t n_iter2, int flags,
                      double* scalars_io, double* out_alpha, double* out_alpha_prev);
 
+/* Bootstrap post-processing (bootstrap.py:51-54 proportions, :75-78 profile estimates):
+ * np.percentile(x, q, axis=0) with numpy's default "linear" method, for x = [n replicates][m positions]
+ * (C order), q = n_q percentiles in [0, 100]; out = [n_q][m].  Bit-identical to numpy for finite inputs
+ * (NaNs are not ordered: inputs are proportions / methylation levels, never NaN).  n <= 19456. */
+int dmf_percentile_axis0(dmf_context* ctx, const double* x, int64_t n, int64_t m, const double* q,
+                         int64_t n_q, int flags, double* out);
+
 /* ---- solver: the outer loop, resident on the device --------------------------------------
  * mdwbssmf_deconv (deconvolution.py:190-223) / unsupervised_deconv's loop (:139-184).
  * create = state init (:192-204); step = up to n_outer outer iterations, stopping early when

@@ -174,3 +174,46 @@ def test_bad_arguments_raise(ctx):
             Solver(p, u, alpha[:-1])
         with pytest.raises(DemethifyHipError):
             p.gather(np.array([0, 100]))
+
+
+@pytest.mark.parametrize("n,m,q", [
+    (500, 1000, [2.5, 97.5]),     # the usual 95 % interval: both order statistics in the register tails
+    (200, 777, [5.0, 95.0]),
+    (40, 513, [0.0, 100.0]),      # extremes: no interpolation
+    (500, 300, [25.0, 75.0]),     # inside the column: ranking kernel
+    (3000, 65, [50.0, 2.5]),      # mixed: one in a tail, one not -> ranking kernel, 4 positions per workgroup
+    (1, 10, [2.5, 97.5]),
+    (2, 10, [30.0]),
+    (33, 129, [10.0, 50.0, 99.0]),  # an odd number of percentiles
+])
+def test_percentile_axis0_is_numpy_bit_for_bit(ctx, n, m, q):
+    """bootstrap.py:51-54 / :75-78: np.percentile(stack, q, axis=0), default "linear" method.  numpy itself is
+    the reference here; the kernel repeats its interpolation operation by operation, so equality is exact."""
+    rs = np.random.RandomState(n + m)
+    x = rs.uniform(size=(n, m))
+    x[:, ::7] = np.round(x[:, ::7], 1)  # heavy ties in some columns
+    x[:, 3 % m] = 0.25                  # a constant column
+    want = np.percentile(x, q, axis=0)
+    got = ctx.percentile_axis0(x, q)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_percentile_axis0_on_device_tensors_and_3d(ctx):
+    torch = pytest.importorskip("torch")
+    rs = np.random.RandomState(0)
+    x = rs.beta(0.5, 0.5, size=(120, 16, 10))  # (replicates, K, S) like the proportions stack
+    want = np.percentile(x, [2.5, 97.5], axis=0)
+    assert np.array_equal(ctx.percentile_axis0(x, [2.5, 97.5]), want)
+    xt = torch.from_numpy(x).to("cuda:0")
+    got = ctx.percentile_axis0(xt, [2.5, 97.5])
+    assert got.is_cuda and np.array_equal(got.cpu().numpy(), want)
+
+
+def test_percentile_axis0_rejects_bad_input(ctx):
+    from demethify_amd._lib import DemethifyHipError
+
+    x = np.zeros((4, 4))
+    with pytest.raises(DemethifyHipError):
+        ctx.percentile_axis0(x, [101.0])
+    with pytest.raises(DemethifyHipError):
+        ctx.percentile_axis0(np.zeros((20000, 2)), [50.0])  # more replicates than the ranking tile holds

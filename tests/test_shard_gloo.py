@@ -63,7 +63,31 @@ def _worker(rank, world, port, out_dir):
     payload = (np.full((3, 2), 5.0),) if rank == 1 else (np.empty((3, 2)),)
     (got,) = shard.broadcast_arrays(payload, 1)
     assert np.array_equal(got, np.full((3, 2), 5.0))
+    # 5. bootstrap post-processing: the stack sharded by replicate is re-partitioned by position range with one
+    #    all-to-all; numpy stands in for the HIP percentile kernel here (no GPU in this suite)
+    full = np.random.RandomState(3).uniform(size=(7, 37))  # 7 replicates over 2 ranks: 4 + 3; 37 positions: 19 + 18
+    mine = full[shard.my_items(7)]
+    got = shard.percentile_over_replicates(mine, 7, [2.5, 97.5], lambda x, q: np.percentile(np.asarray(x), q, axis=0))
+    if rank == 0:
+        assert np.array_equal(got, np.percentile(full, [2.5, 97.5], axis=0))
+    else:
+        assert got is None
+    # fewer replicates than ranks: a rank with an empty share still takes part in the exchange
+    one = full[:1]
+    got = shard.percentile_over_replicates(one[shard.my_items(1)], 1, [50.0],
+                                           lambda x, q: np.percentile(np.asarray(x), q, axis=0))
+    assert (np.array_equal(got, one)) if rank == 0 else got is None
     dist.destroy_process_group()
+
+
+def test_split_positions_cover_everything():
+    from demethify_amd.shard import split_positions
+
+    for m, world in [(37, 2), (5, 8), (16, 4), (0, 3)]:
+        r = split_positions(m, world)
+        assert len(r) == world and r[0][0] == 0 and r[-1][1] == m
+        assert all(a1 == b0 for (_, b0), (a1, _) in zip(r, r[1:]))
+        assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
 
 
 def test_sharded_restarts_match_serial(tmp_path):
