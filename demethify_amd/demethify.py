@@ -22,6 +22,8 @@ from time import time
 import numpy as np
 import pandas as pd
 
+from . import tables
+
 logo = r"""
     ____                      __  __    _ ____
    / __ \___  ____ ___  ___  / /_/ /_  (_) __/_  __
@@ -55,7 +57,8 @@ def build_parser():
 
 
 def read_inputs(args):
-    """demethify.py:102-143: bedmethyl (tab separated, percent) or csv (fractions) input."""
+    """demethify.py:102-143: bedmethyl (tab separated, percent) or csv (fractions) input.  The per-sample files
+    are parsed in parallel (and 1 / world of them per rank when distributed): demethify_amd/tables.py."""
     ref, header = None, []
     sep = '\t' if args.bedmethyl else ','
     if args.ref:
@@ -66,17 +69,8 @@ def read_inputs(args):
             table = table.fillna(0)
         header = list(table.columns)
         ref = table.values
-    freqs, counts = [], []
-    for path in args.methfreq:
-        temp = pd.read_csv(path, sep=sep)
-        if not args.bedmethyl and temp.shape[1] == 1:
-            temp["valid_coverage"] = 1
-        if args.fillna:
-            temp = temp.fillna(0)
-        scale = 100 if args.bedmethyl else 1
-        freqs.append(temp["percent_modified"].values / scale if args.bedmethyl else temp["percent_modified"].values)
-        counts.append(temp["valid_coverage"].values)
-    return ref, header, np.column_stack(freqs), np.column_stack(counts)
+    meth_f, counts = tables.read_samples(args.methfreq, bool(args.bedmethyl), bool(args.fillna))
+    return ref, header, meth_f, counts
 
 
 def _init_distributed():

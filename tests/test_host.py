@@ -76,3 +76,40 @@ def test_unsupervised_uniform_keeps_upstream_nameerror(toy):
     u, a = _init_unsupervised("uniform_", V, 4, 1)
     wu, wa = osol.init_unsupervised("uniform_", V, 4, 1)
     assert np.array_equal(u, wu) and np.array_equal(a, wa)
+
+
+def test_table_reader_equals_upstream_loop(tmp_path, monkeypatch):
+    """demethify.py:103-143 restated with usecols + worker processes: same values, dtypes and layout as the
+    reference's read_csv / column_stack loop, for bedmethyl and for csv input."""
+    import pandas as pd
+
+    from conftest import UPSTREAM
+    from demethify_amd import tables
+
+    paths = [str(UPSTREAM / "output_gen" / f"sample{i}.bed") for i in range(1, 11)]
+    cols = [pd.read_csv(p, sep="\t") for p in paths]
+    want_f = np.column_stack([t["percent_modified"].values / 100 for t in cols])
+    want_c = np.column_stack([t["valid_coverage"].values for t in cols])
+    for workers in ("1", "4"):
+        monkeypatch.setenv("DEMETHIFY_IO_WORKERS", workers)
+        got_f, got_c = tables.read_samples(paths, True, False)
+        assert np.array_equal(got_f, want_f) and np.array_equal(got_c, want_c)
+        assert got_c.dtype == want_c.dtype and got_f.flags["C_CONTIGUOUS"] and got_c.flags["C_CONTIGUOUS"]
+    monkeypatch.delenv("DEMETHIFY_IO_WORKERS")
+    # csv: a single-column file gets coverage 1 (demethify.py:134-135); NaN handling follows --fillna
+    one = tmp_path / "one.csv"
+    one.write_text("percent_modified\n0.25\n\n0.5\n".replace("\n\n", "\nNaN\n"))
+    two = tmp_path / "two.csv"
+    two.write_text("percent_modified,valid_coverage\n0.1,7\n0.2,\n0.3,9\n")
+    f, c = tables.read_samples([str(one), str(two)], False, True)
+    assert np.array_equal(f, [[0.25, 0.1], [0.0, 0.2], [0.5, 0.3]]) and np.array_equal(c, [[1, 7], [1, 0], [1, 9]])
+    f, c = tables.read_samples([str(one), str(two)], False, False)
+    assert np.isnan(f[1, 0]) and np.isnan(c[1, 1]) and c.dtype == np.float64
+    bad = tmp_path / "bad.csv"
+    bad.write_text("a,b\n1,2\n")
+    with pytest.raises(KeyError):
+        tables.read_samples([str(bad)], False, False)
+    short = tmp_path / "short.csv"
+    short.write_text("percent_modified,valid_coverage\n0.1,7\n")
+    with pytest.raises(ValueError):
+        tables.read_samples([str(two), str(short)], False, False)

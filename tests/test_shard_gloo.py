@@ -77,6 +77,12 @@ def _worker(rank, world, port, out_dir):
     got = shard.percentile_over_replicates(one[shard.my_items(1)], 1, [50.0],
                                            lambda x, q: np.percentile(np.asarray(x), q, axis=0))
     assert (np.array_equal(got, one)) if rank == 0 else got is None
+    # 6. input tables: each rank parses its share of the sample files, the columns are exchanged as tensors
+    from demethify_amd import tables
+
+    paths = [str(ROOT / "tests" / "golden" / "upstream" / "output_gen" / f"sample{i}.bed") for i in range(1, 8)]
+    meth_f, counts = tables.read_samples(paths, True, False)
+    np.savez(os.path.join(out_dir, f"tables{rank}.npz"), meth_f=meth_f, counts=counts)
     dist.destroy_process_group()
 
 
@@ -101,6 +107,17 @@ def test_sharded_restarts_match_serial(tmp_path):
         assert int(z["best_k"]) == best
         assert np.array_equal(z["costs"], costs)
         assert np.array_equal(z["u"], serial[best][0]) and np.array_equal(z["alpha"], serial[best][1])
+    # the sharded table read equals upstream's loop (demethify.py:110-119) on every rank, dtypes included
+    import pandas as pd
+
+    cols = [pd.read_csv(ROOT / "tests" / "golden" / "upstream" / "output_gen" / f"sample{i}.bed", sep="\t")
+            for i in range(1, 8)]
+    want_f = np.column_stack([t["percent_modified"].values / 100 for t in cols])
+    want_c = np.column_stack([t["valid_coverage"].values for t in cols])
+    for rank in range(world):
+        z = np.load(tmp_path / f"tables{rank}.npz")
+        assert np.array_equal(z["meth_f"], want_f) and np.array_equal(z["counts"], want_c)
+        assert z["counts"].dtype == want_c.dtype and z["meth_f"].flags["C_CONTIGUOUS"]
 
 
 def test_restart_seed_convention():
