@@ -77,6 +77,8 @@ struct dmf_solver {
     int mode = 0;
     int u_path = 0;         // 0 MFMA, 1 Gram-form VALU, 2 schedule-faithful direct steps
     bool use_gram_spec = false;
+    bool use_gram_mfma = false;
+    bool use_u_big = false;      // 9 <= n_u <= 26: matrix-core u phase with M_i in LDS  // shapes beyond the lane-per-sample kernel's registers: MFMA Gram
     bool use_fused = false;
     double* purity = nullptr;  // S per-sample known-block masses: set => Frank-Wolfe alpha phase
     double* u2_partials = nullptr;
@@ -244,6 +246,11 @@ int enqueue_u_phase(dmf_solver* s, int n_iter2) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
     FamilyScope scope(ctx, DMF_KERNEL_ROWPASS);
+    if (s->use_u_big && dmf::u_phase_big_supported((int)p->S, (int)p->n_c, (int)s->n_u, n_iter2)) {
+        HIP_TRY(dmf::launch_u_phase_big(p->V, p->D, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, (int)p->S,
+                                        (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
+        return DMF_OK;
+    }
     if (s->u_path == 0) {
         HIP_TRY(dmf::launch_u_phase_mfma(p->V, p->D, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N,
                                          (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
@@ -277,6 +284,15 @@ int enqueue_gram(dmf_solver* s) {
         return DMF_OK;
     }
     dmf::GramJobTable jobs{s->job_k, s->job_l, s->job_dst, s->n_jobs};
+    if (s->use_gram_mfma) {
+        int ny = 0;
+        HIP_TRY(dmf::launch_gram_mfma(p->V, p->D, p->Rt, s->u, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, jobs,
+                                      s->n_jobs - (int)s->n_u, s->slab, s->slab_doubles, &s->state->done, &ny,
+                                      ctx->stream));
+        HIP_TRY(dmf::launch_gram_reduce(s->slab, ny, s->n_jobs, (int)p->S, s->job_dst, s->gb, &s->state->done,
+                                        ctx->stream));
+        return DMF_OK;
+    }
     HIP_TRY(dmf::launch_gram(p->V, p->D, p->Rt, s->u, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, jobs,
                              s->slab, s->slab_doubles, s->gb, &s->state->done, ctx->stream));
     return DMF_OK;
@@ -598,6 +614,8 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     else if (ctx->generic_level != 2 && dmf::u_phase_gram_supported((int)S, (int)n_c, (int)n_u)) s->u_path = 1;
     else s->u_path = 2;
     s->use_gram_spec = fast && dmf::gram_u_supported((int)n_c, (int)n_u);
+    s->use_gram_mfma = fast && !s->use_gram_spec;
+    s->use_u_big = fast && s->u_path != 0 && dmf::u_phase_big_supported((int)S, (int)n_c, (int)n_u, 64);
     s->use_fused = ctx->generic_level == 0 && p->d_f32_exact && N >= 16 &&
                    dmf::rowpass_fused_supported((int)S, (int)n_c, (int)n_u) &&
                    dmf::u_phase_mfma_supported((int)S, (int)n_c, (int)n_u) && dmf::gram_u_supported((int)n_c, (int)n_u);
@@ -621,6 +639,10 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     if (s->use_gram_spec) {
         const int64_t spec = dmf::gram_u_slab_doubles(N, (int)S, (int)n_c, (int)n_u);
         if (spec > s->slab_doubles) s->slab_doubles = spec;
+    }
+    if (s->use_gram_mfma) {
+        const int64_t need = dmf::gram_mfma_slab_doubles(N, (int)S, s->n_jobs);
+        if (need > s->slab_doubles) s->slab_doubles = need;
     }
     if (s->use_fused) {
         const int64_t spec = dmf::rowpass_fused_slab_doubles(N - (N & 15), (int)S, (int)n_c, (int)n_u) +

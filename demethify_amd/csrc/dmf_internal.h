@@ -132,6 +132,19 @@ hipError_t launch_scatter_known_block(const double* gb_known, double* gb, int n_
 hipError_t launch_init_state(SolverState* state, const double* consts, const double* alpha,
                              int S, int n_c, int n_u, hipStream_t st);
 
+// u phase for 9 <= n_u <= 26 unknown types on the matrix cores (dmf_kernels_rowpass_big.hip); Rtp = padded R_trunc
+bool u_phase_big_supported(int S, int n_c, int n_u, int n_iter2);
+hipError_t launch_u_phase_big(const double* V, const double* D, const double* Rtp, const double* alpha, double* u,
+                              double* u_prev, const SolverState* state, int64_t N, int S, int n_c, int n_u,
+                              int n_iter2, int mode, hipStream_t st);
+
+// any-shape Gram accumulation on the matrix cores (dmf_kernels_gram_mfma.hip): jobs [0, n_dense) have l < K,
+// the rest are the "v" column; the slab ([ny][count][S]) is then summed by launch_gram_reduce
+hipError_t launch_gram_mfma(const double* V, const double* D, const double* Rt, const double* u, int64_t N, int S,
+                            int n_c, int n_u, GramJobTable jobs, int n_dense, double* slab, int64_t slab_doubles,
+                            const int* done_flag, int* ny_out, hipStream_t st);
+int64_t gram_mfma_slab_doubles(int64_t N, int S, int n_jobs);
+
 // two percentiles over axis 0 of x[n][m] -> out0[m], out1[m] (out1 may be null); dmf_kernels_percentile.hip
 hipError_t launch_percentile_pair(const double* x, int64_t n, int64_t m, PercentilePlan p0, PercentilePlan p1,
                                   double* out0, double* out1, hipStream_t st);

@@ -16,7 +16,7 @@
 // its share of ||u||_F^2; k_gram_reduce sums the slabs in fixed order.
 //
 // Preconditions (checked by the launcher): N % 16 == 0 (the caller runs the ragged tail, < 16 rows, through
-// the unfused kernels), S % 4 == 0, S <= 256, n_c <= 16, n_u <= 8, counts exactly representable in f32;
+// the unfused kernels), S % 4 == 0, S <= 256, n_c <= 16, n_u <= 4, counts exactly representable in f32;
 // `Rtp` is the problem's zero-padded copy of R_trunc (row stride 4 NKC).
 #include "dmf_device.h"
 #include "dmf_internal.h"
@@ -582,7 +582,9 @@ hipError_t launch_finish_u_norm(const double* u2_partials, int n, SolverState* s
 }
 
 bool rowpass_fused_supported(int S, int n_c, int n_u) {
-    if ((S & 3) != 0 || S > 256 || n_c > 16 || n_u < 1 || n_u > 8) return false;
+    // n_u <= 4: beyond that phase B needs two passes per block and the accumulators spill; measured at
+    // 5e5 x 128, n_c = 0: n_u = 5 / 6 / 8 run 0.96 / 1.42 / 2.1 ms fused against 0.62 / 0.68 / 1.18 ms unfused
+    if ((S & 3) != 0 || S > 256 || n_c > 16 || n_u < 1 || n_u > 4) return false;
     const int nct = (n_c + 3) / 4 * 4;
     return nct * n_u + n_u * (n_u + 1) / 2 + n_u <= 80;
 }
@@ -642,7 +644,7 @@ static hipError_t launch_fused_nkc(int n_u, const double* V, const double* D, co
     case NU_:                                                                                              \
         return launch_fused_t<NKC, NU_>(V, D, Rtp, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, slab, \
                                         u2_partials, grid_out, st);
-        DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4) DMF_CASE(5) DMF_CASE(6) DMF_CASE(7) DMF_CASE(8)
+        DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4)
 #undef DMF_CASE
         default: return hipErrorInvalidValue;
     }

@@ -134,7 +134,7 @@ static void gram_u_geometry(int64_t N, int S, int* nsx, int* ny, int64_t* rows_p
 }
 
 bool gram_u_supported(int n_c, int n_u) {
-    if (n_u < 1 || n_u > 8 || n_c > 16) return false;
+    if (n_u < 1 || n_u > 13 || n_c > 16) return false;  // (13: the register budget below with n_c = 0)
     const int nct = (n_c + 3) / 4 * 4;
     return nct * n_u + n_u * (n_u + 1) / 2 + n_u <= 112;
 }
@@ -171,6 +171,7 @@ static hipError_t launch_gram_u_nct(int n_u, const double* V, const double* D, c
         else                                                                                \
             return hipErrorInvalidValue;
         DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4) DMF_CASE(5) DMF_CASE(6) DMF_CASE(7) DMF_CASE(8)
+        DMF_CASE(9) DMF_CASE(10) DMF_CASE(11) DMF_CASE(12) DMF_CASE(13)
 #undef DMF_CASE
         default: return hipErrorInvalidValue;
     }

@@ -1,0 +1,216 @@
+// Any-shape per-sample weighted Gram accumulation on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), for the
+// shapes whose accumulators do not fit the registers of the lane-per-sample kernel (dmf_kernels_gram.hip):
+// many unknown types (the --ic sweep goes to n_u = 25, ic.py:171) or many known x unknown pairs.
+//
+// Every job of the solver's table is one row of the per-sample packed Gram that involves u:
+//     G[(k, l)][s] = sum_r f_k(r) f_l(r) d[r][s]        f_x(r) = R_trunc[r][x] (x < n_c) or u[r][x - n_c]
+//     b[k][s]      = sum_r f_k(r) (d[r][s] v[r][s])     (jobs with l = K, the "v" column)
+// i.e. a GEMM  [jobs x rows] x [rows x samples]  whose A operand is a product of two row features (formed on
+// the fly: one multiply per operand) and whose B operand is the D tile itself (or D * V for the b rows, which
+// run as a second, small launch of the same kernel so that the main pass reads D only).
+//
+// Workgroup = 8 waves on one 64-sample column group and one chunk of rows.  Wave w owns MTW consecutive
+// 16-job tiles and all four 16-sample tiles of the group: 16 MTW accumulators per lane, live over the whole
+// chunk.  Per 16-row block the 16 x K row features are staged in LDS once for the workgroup; the D operands of
+// the next block are prefetched into registers while the MFMAs of the current one run.
+// Layouts (tools/mfma_probe.hip): A[i][k]: lane (i = l & 15, k = l >> 4); B[k][j]: lane (k = l >> 4, j = l & 15);
+// C register r of lane l = C[(l >> 4) + 4 r][l & 15].
+// Output: slab[y][job][s] per row chunk y, summed in fixed order by k_gram_reduce: deterministic.
+#include "dmf_internal.h"
+
+namespace dmf {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int kGramMfmaWaves = 8;
+constexpr int kGramMfmaMaxTilesPerWave = 4;  // 16 accumulators per tile: 5 and more spill
+
+template <int MTW, bool VJOBS>
+__global__ __launch_bounds__(512) void k_gram_mfma(const double* __restrict__ V, const double* __restrict__ D,
+                                                   const double* __restrict__ Rt, const double* __restrict__ u,
+                                                   int64_t N, int S, int n_c, int n_u,
+                                                   const short* __restrict__ job_k, const short* __restrict__ job_l,
+                                                   int n_jobs, int job_begin, int job_end, int64_t rows_per_chunk,
+                                                   double* __restrict__ slab, const int* __restrict__ done_flag) {
+    __shared__ double feat[2][16 * (kMaxK + 1)];  // [buffer][row][feature], row stride K + 1
+    if (done_flag != nullptr && *done_flag) return;
+    const int K = n_c + n_u, FS = K + 1;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int s0 = blockIdx.x * 64;
+
+    // this lane's job in each of the wave's tiles (A operand row i16), and its two features
+    int fk[MTW], fl[MTW];
+    double keep[MTW];
+#pragma unroll
+    for (int x = 0; x < MTW; ++x) {
+        const int job = job_begin + (wave * MTW + x) * 16 + i16;
+        const bool ok = job < job_end;
+        fk[x] = ok ? job_k[job] : 0;
+        fl[x] = ok ? job_l[job] : 0;
+        if (VJOBS) fl[x] = fk[x];  // the "v" column is not a row feature: A = f_k alone
+        keep[x] = ok ? 1.0 : 0.0;
+    }
+    // this lane's B-operand columns (clamped: out-of-range samples are computed and never stored)
+    int col[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int c = s0 + 16 * nt + i16;
+        col[nt] = c < S ? c : S - 1;
+    }
+
+    v4d acc[MTW][4];
+#pragma unroll
+    for (int x = 0; x < MTW; ++x)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[x][nt] = v4d{0.0, 0.0, 0.0, 0.0};
+
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < N ? r0 + rows_per_chunk : N;
+    if (r0 >= r1) return;  // (whole workgroup: no barrier is skipped by part of it)
+
+    auto stage = [&](int buf, int64_t row0) {  // 16 x K features of rows row0 .. row0 + 15 (zero past N)
+        for (int idx = threadIdx.x; idx < 16 * K; idx += 512) {
+            const int r = idx / K, x = idx - r * K;
+            const int64_t row = row0 + r;
+            double f = 0.0;
+            if (row < N) f = x < n_c ? Rt[row * n_c + x] : u[row * n_u + (x - n_c)];
+            feat[buf][r * FS + x] = f;
+        }
+    };
+    auto load_b = [&](int64_t row0, double (&b)[4][4]) {  // B operands of the 4 k-steps x 4 sample tiles
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            int64_t row = row0 + 4 * st + kq;
+            row = row < N ? row : N - 1;  // rows past N meet zero features
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const double d = D[row * S + col[nt]];
+                b[st][nt] = VJOBS ? d * V[row * S + col[nt]] : d;
+            }
+        }
+    };
+
+    double bcur[4][4], bnext[4][4];
+    stage(0, r0);
+    load_b(r0, bcur);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t row0 = r0; row0 < r1; row0 += 16, buf ^= 1) {
+        const bool more = row0 + 16 < r1;
+        if (more) {
+            stage(buf ^ 1, row0 + 16);  // the other buffer: its readers finished before the last barrier
+            load_b(row0 + 16, bnext);
+        }
+        const double* __restrict__ f = feat[buf];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            double a[MTW];
+#pragma unroll
+            for (int x = 0; x < MTW; ++x) {
+                const double fa = f[(4 * st + kq) * FS + fk[x]];
+                const double fb = VJOBS ? keep[x] : keep[x] * f[(4 * st + kq) * FS + fl[x]];
+                a[x] = fa * fb;
+            }
+#pragma unroll
+            for (int x = 0; x < MTW; ++x)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[x][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], bcur[st][nt], acc[x][nt], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) bcur[st][nt] = bnext[st][nt];
+        }
+        __syncthreads();
+    }
+
+    // C register r of lane l: job row (l >> 4) + 4 r of the tile, sample column l & 15
+#pragma unroll
+    for (int x = 0; x < MTW; ++x) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int job = job_begin + (wave * MTW + x) * 16 + kq + 4 * r;
+            if (job < job_end) {
+                double* __restrict__ out = slab + ((int64_t)blockIdx.y * n_jobs + job) * S;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int s = s0 + 16 * nt + i16;
+                    if (s < S) out[s] = acc[x][nt][r];
+                }
+            }
+        }
+    }
+}
+
+static void gram_mfma_geometry(int64_t N, int S, int* nsx, int* ny, int64_t* rows_per_chunk) {
+    *nsx = (S + 63) / 64;
+    int64_t want = 256 / (*nsx);  // one 8-wave workgroup per CU
+    if (want < 1) want = 1;
+    int64_t rpc = (N + want - 1) / want;
+    rpc = (rpc + 15) / 16 * 16;
+    if (rpc < 64) rpc = 64;
+    *rows_per_chunk = rpc;
+    *ny = (int)((N + rpc - 1) / rpc);
+}
+
+int64_t gram_mfma_slab_doubles(int64_t N, int S, int n_jobs) {
+    int nsx, ny;
+    int64_t rpc;
+    gram_mfma_geometry(N, S, &nsx, &ny, &rpc);
+    return (int64_t)ny * n_jobs * S;
+}
+
+template <bool VJOBS>
+static hipError_t launch_gram_mfma_range(const double* V, const double* D, const double* Rt, const double* u,
+                                         int64_t N, int S, int n_c, int n_u, const short* job_k, const short* job_l,
+                                         int n_jobs, int job_begin, int job_end, double* slab, const int* done_flag,
+                                         hipStream_t st) {
+    int nsx, ny;
+    int64_t rpc;
+    gram_mfma_geometry(N, S, &nsx, &ny, &rpc);
+    const dim3 grid(nsx, ny), block(kGramMfmaWaves * 64);
+    while (job_begin < job_end) {
+        const int tiles = (job_end - job_begin + 15) / 16;
+        int mtw = (tiles + kGramMfmaWaves - 1) / kGramMfmaWaves;
+        if (mtw > kGramMfmaMaxTilesPerWave) mtw = kGramMfmaMaxTilesPerWave;
+        int end = job_begin + mtw * kGramMfmaWaves * 16;
+        if (end > job_end) end = job_end;
+#define DMF_CASE(M_)                                                                                               \
+    case M_:                                                                                                       \
+        hipLaunchKernelGGL((k_gram_mfma<M_, VJOBS>), grid, block, 0, st, V, D, Rt, u, N, S, n_c, n_u, job_k, job_l, \
+                           n_jobs, job_begin, end, rpc, slab, done_flag);                                          \
+        break;
+        switch (mtw) {
+            DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4)
+            default: return hipErrorInvalidValue;
+        }
+#undef DMF_CASE
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        job_begin = end;
+    }
+    return hipSuccess;
+}
+
+// jobs [0, n_dense) have B = D, jobs [n_dense, count) are the "v" column (B = D * V); ny_out = slab rows per job
+hipError_t launch_gram_mfma(const double* V, const double* D, const double* Rt, const double* u, int64_t N, int S,
+                            int n_c, int n_u, GramJobTable jobs, int n_dense, double* slab, int64_t slab_doubles,
+                            const int* done_flag, int* ny_out, hipStream_t st) {
+    if (jobs.count <= 0 || n_c + n_u > kMaxK) return hipErrorInvalidValue;
+    int nsx, ny;
+    int64_t rpc;
+    gram_mfma_geometry(N, S, &nsx, &ny, &rpc);
+    if ((int64_t)ny * jobs.count * S > slab_doubles) return hipErrorInvalidValue;
+    *ny_out = ny;
+    hipError_t e = launch_gram_mfma_range<false>(V, D, Rt, u, N, S, n_c, n_u, jobs.k_idx, jobs.l_idx, jobs.count, 0,
+                                                 n_dense, slab, done_flag, st);
+    if (e != hipSuccess) return e;
+    return launch_gram_mfma_range<true>(V, D, Rt, u, N, S, n_c, n_u, jobs.k_idx, jobs.l_idx, jobs.count, n_dense,
+                                        jobs.count, slab, done_flag, st);
+}
+
+}  // namespace dmf

@@ -90,6 +90,45 @@ def test_fixed_iteration_parity(ctx, N, S, n_c, n_u, T1, generic):
     assert cost == pytest.approx(osol.weighted_cost(V, R_final, wa, D), rel=1e-9)
 
 
+BIG_CASES = [  # (N, S, n_c, n_u, T1): 9 <= n_u <= 26 runs the matrix-core u phase with M_i in LDS + the MFMA Gram
+    (650, 24, 0, 9, 3), (1000, 100, 0, 13, 2), (530, 37, 12, 9, 3), (777, 64, 5, 16, 2), (333, 130, 0, 17, 2),
+    (600, 48, 3, 20, 2), (512, 20, 0, 25, 2), (500, 128, 16, 26, 2), (400, 30, 1, 27, 2),
+]
+
+
+@pytest.mark.parametrize("generic", [0, 3])
+@pytest.mark.parametrize("N,S,n_c,n_u,T1", BIG_CASES)
+def test_many_unknown_types_parity(ctx, N, S, n_c, n_u, T1, generic):
+    """The --ic sweep goes to n_u = 25 (ic.py:171): same parity bar as the small shapes, ragged N and S included;
+    n_u = 27 falls back to the schedule-faithful u steps."""
+    from demethify_amd import _lib as L
+    from demethify_amd.device import Problem
+    from demethify_amd.deconvolution import solve_problem
+
+    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=21, depth=30)
+    if n_c:
+        u0, R, a0 = osol.init_partial("uniform_", V, D, Rt, n_u, seed=2)
+        wu, wa = osol.solve_partial(u0.copy(), R, a0.copy(), V, D, Rt, n_u, T1, 20, 0.0,
+                                    project=osol.simplex_project_columns_fast)
+        mode = L.DMF_MODE_PARTIAL
+    else:
+        u0, a0 = osol.init_unsupervised("uniform_", V, n_u, seed=2)
+        wu, wa = osol.solve_unsupervised(V, n_u, D, "uniform_", T1, 20, 0.0, init=(u0.copy(), a0.copy()),
+                                         project=osol.simplex_project_columns_fast)
+        mode = L.DMF_MODE_UNSUPERVISED
+    ctx.set_generic(generic)
+    try:
+        with Problem(ctx, V, D, Rt if n_c else None) as p:
+            u, alpha, cost, iters = solve_problem(p, u0, a0, mode, T1, 20, 0.0, return_info=True)
+    finally:
+        ctx.set_generic(0)
+    assert iters == T1
+    assert rel_err(alpha, wa) < TIGHT and np.abs(alpha - wa).max() < TIGHT
+    assert np.abs(u - wu).max() < TIGHT
+    R_final = np.c_[Rt, wu] if n_c else wu
+    assert cost == pytest.approx(osol.weighted_cost(V, R_final, wa, D), rel=1e-9)
+
+
 def test_natural_stop_synthetic(ctx):
     from demethify_amd import deconvolution as dd
 
@@ -106,7 +145,7 @@ def test_natural_stop_synthetic(ctx):
 
 
 def test_many_unknowns_uses_fallback_path(ctx):
-    """n_u > 8 runs the schedule-faithful u kernels and the runtime-K alpha kernel (K = 5 + 12)."""
+    """n_u > 8 through the reference-named entry point (K = 5 + 12: runtime-K alpha kernel)."""
     from demethify_amd import deconvolution as dd
 
     V, D, Rt = osol.synthetic_problem(800, 14, 5, 12, seed=9, depth=25)
