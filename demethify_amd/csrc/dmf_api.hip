@@ -50,7 +50,7 @@ struct dmf_context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    bool profiling = false;
+    unsigned profiling = 0;  // bit f: record events around the launches of kernel family f
     int generic_level = 0;  // 0 fused row pass, 1 any-shape Gram-form kernels, 2 schedule-faithful u steps,
                             // 3 separate MFMA row pass + one-pass Gram (the pieces the fused kernel is made of)
     double* scratch = nullptr;  // 4096 doubles of reduction scratch
@@ -117,7 +117,7 @@ struct FamilyScope {
     FamilyClock* c = nullptr;
     int slot = -1;
     FamilyScope(dmf_context* ctx_, int family) : ctx(ctx_) {
-        if (!ctx->profiling) return;
+        if (!((ctx->profiling >> family) & 1u)) return;
         c = &ctx->clocks[family];
         if (c->start.empty()) {
             c->start.resize(kEventPool);
@@ -456,7 +456,9 @@ int dmf_context_set_profiling(dmf_context* ctx, int enabled) {
     DMF_TRY(check_ctx(ctx));
     if (!enabled)
         for (auto& c : ctx->clocks) DMF_TRY(clock_drain(ctx, c));
-    ctx->profiling = enabled != 0;
+    // 0 = off, 1 = every family, otherwise a mask with bit (1 + family) set for the families to time
+    // (2 = DMF_KERNEL_ROWPASS only, ...): each timed launch costs two event records on the stream
+    ctx->profiling = enabled == 0 ? 0u : enabled == 1 ? ~0u : (unsigned)enabled >> 1;
     return DMF_OK;
 }
 

@@ -61,8 +61,13 @@ class Context:
     def synchronize(self):
         L.check(self._lib.dmf_context_synchronize(self._h), "dmf_context_synchronize")
 
-    def set_profiling(self, enabled: bool):
-        L.check(self._lib.dmf_context_set_profiling(self._h, int(bool(enabled))), "dmf_context_set_profiling")
+    def set_profiling(self, enabled, families=None):
+        """Record HIP events around kernel launches: all families, or only ``families`` (indices into
+        ``_lib.KERNEL_FAMILIES``) — every timed launch costs two event records on the stream."""
+        mode = int(bool(enabled))
+        if mode and families is not None:
+            mode = sum(1 << (1 + int(f)) for f in families)
+        L.check(self._lib.dmf_context_set_profiling(self._h, mode), "dmf_context_set_profiling")
 
     def set_generic(self, level: int):
         """Kernel selection for tests: 0 fastest (fused FP64-MFMA row pass), 1 any-shape Gram-form kernels,

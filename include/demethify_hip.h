@@ -73,7 +73,8 @@ int dmf_abi_version(void);
 int dmf_context_create(int device, void* stream, dmf_context** out);
 int dmf_context_destroy(dmf_context* ctx);
 int dmf_context_synchronize(dmf_context* ctx);
-/* Record HIP events around every launch of the kernel families above (costs a sync per read). */
+/* Record HIP events around the launches of the kernel families above (costs a sync per read).
+ * enabled: 0 = off, 1 = every family, else a mask with bit (1 + family) set, e.g. 2 = DMF_KERNEL_ROWPASS only. */
 int dmf_context_set_profiling(dmf_context* ctx, int enabled);
 int dmf_context_kernel_time(dmf_context* ctx, int family, double* total_ms, int64_t* launches);
 int dmf_context_reset_kernel_time(dmf_context* ctx);
