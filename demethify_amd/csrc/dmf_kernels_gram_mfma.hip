@@ -6,8 +6,8 @@
 //     G[(k, l)][s] = sum_r f_k(r) f_l(r) d[r][s]        f_x(r) = R_trunc[r][x] (x < n_c) or u[r][x - n_c]
 //     b[k][s]      = sum_r f_k(r) (d[r][s] v[r][s])     (jobs with l = K, the "v" column)
 // i.e. a GEMM  [jobs x rows] x [rows x samples]  whose A operand is a product of two row features (formed on
-// the fly: one multiply per operand) and whose B operand is the D tile itself (or D * V for the b rows, which
-// run as a second, small launch of the same kernel so that the main pass reads D only).
+// the fly: one multiply per operand) and whose B operand is the D tile itself, or D * V for the b rows: those
+// tiles go to waves of their own (a wave never mixes the two kinds), so only these waves load V as well.
 //
 // Workgroup = 8 waves on one 64-sample column group and one chunk of rows.  Wave w owns MTW consecutive
 // 16-job tiles and all four 16-sample tiles of the group: 16 MTW accumulators per lane, live over the whole
@@ -25,12 +25,15 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kGramMfmaWaves = 8;
 constexpr int kGramMfmaMaxTilesPerWave = 4;  // 16 accumulators per tile: 5 and more spill
 
-template <int MTW, bool VJOBS>
+// Waves [0, v_wave0) take the jobs [job_begin, job_end) (B = D), waves [v_wave0, 8) the "v" jobs
+// [vjob_begin, vjob_end) (B = D * V); MTW consecutive 16-job tiles per wave.
+template <int MTW>
 __global__ __launch_bounds__(512) void k_gram_mfma(const double* __restrict__ V, const double* __restrict__ D,
                                                    const double* __restrict__ Rt, const double* __restrict__ u,
                                                    int64_t N, int S, int n_c, int n_u,
                                                    const short* __restrict__ job_k, const short* __restrict__ job_l,
-                                                   int n_jobs, int job_begin, int job_end, int64_t rows_per_chunk,
+                                                   int n_jobs, int job_begin, int job_end, int vjob_begin,
+                                                   int vjob_end, int v_wave0, int64_t rows_per_chunk,
                                                    double* __restrict__ slab, const int* __restrict__ done_flag) {
     __shared__ double feat[2][16 * (kMaxK + 1)];  // [buffer][row][feature], row stride K + 1
     if (done_flag != nullptr && *done_flag) return;
@@ -39,14 +42,17 @@ __global__ __launch_bounds__(512) void k_gram_mfma(const double* __restrict__ V,
     const int lane = threadIdx.x & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     const int s0 = blockIdx.x * 64;
+    const bool VJOBS = wave >= v_wave0;  // wave-uniform
+    const int tile0 = VJOBS ? (wave - v_wave0) * MTW : wave * MTW;
+    const int jb = VJOBS ? vjob_begin : job_begin, je = VJOBS ? vjob_end : job_end;
 
     // this lane's job in each of the wave's tiles (A operand row i16), and its two features
     int fk[MTW], fl[MTW];
     double keep[MTW];
 #pragma unroll
     for (int x = 0; x < MTW; ++x) {
-        const int job = job_begin + (wave * MTW + x) * 16 + i16;
-        const bool ok = job < job_end;
+        const int job = jb + (tile0 + x) * 16 + i16;
+        const bool ok = job < je;
         fk[x] = ok ? job_k[job] : 0;
         fl[x] = ok ? job_l[job] : 0;
         if (VJOBS) fl[x] = fk[x];  // the "v" column is not a row feature: A = f_k alone
@@ -70,13 +76,25 @@ __global__ __launch_bounds__(512) void k_gram_mfma(const double* __restrict__ V,
     const int64_t r1 = r0 + rows_per_chunk < N ? r0 + rows_per_chunk : N;
     if (r0 >= r1) return;  // (whole workgroup: no barrier is skipped by part of it)
 
-    auto stage = [&](int buf, int64_t row0) {  // 16 x K features of rows row0 .. row0 + 15 (zero past N)
-        for (int idx = threadIdx.x; idx < 16 * K; idx += 512) {
+    // Row features travel global -> registers -> LDS in two steps one block apart (a thread carries at most
+    // 16 K / 512 = 2 of them), so that no wave ever waits for a load it has just issued.
+    auto fetch_feat = [&](int64_t row0, double (&fr)[2]) {  // 16 x K features of rows row0 .. row0 + 15 (zero past N)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int idx = threadIdx.x + 512 * h;
             const int r = idx / K, x = idx - r * K;
             const int64_t row = row0 + r;
             double f = 0.0;
-            if (row < N) f = x < n_c ? Rt[row * n_c + x] : u[row * n_u + (x - n_c)];
-            feat[buf][r * FS + x] = f;
+            if (idx < 16 * K && row < N) f = x < n_c ? Rt[row * n_c + x] : u[row * n_u + (x - n_c)];
+            fr[h] = f;
+        }
+    };
+    auto park_feat = [&](int buf, const double (&fr)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int idx = threadIdx.x + 512 * h;
+            const int r = idx / K, x = idx - r * K;
+            if (idx < 16 * K) feat[buf][r * FS + x] = fr[h];
         }
     };
     auto load_b = [&](int64_t row0, double (&b)[4][4]) {  // B operands of the 4 k-steps x 4 sample tiles
@@ -85,23 +103,33 @@ __global__ __launch_bounds__(512) void k_gram_mfma(const double* __restrict__ V,
             int64_t row = row0 + 4 * st + kq;
             row = row < N ? row : N - 1;  // rows past N meet zero features
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const double d = D[row * S + col[nt]];
-                b[st][nt] = VJOBS ? d * V[row * S + col[nt]] : d;
+            for (int nt = 0; nt < 4; ++nt) b[st][nt] = D[row * S + col[nt]];
+            if (VJOBS) {  // wave-uniform: only the waves that own b rows read V
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) b[st][nt] *= V[row * S + col[nt]];
             }
         }
     };
 
-    double bcur[4][4], bnext[4][4];
-    stage(0, r0);
-    load_b(r0, bcur);
+    // software pipeline over 16-row blocks: while block i runs on the matrix cores, the D operands of block
+    // i + 1 and the row features of block i + 2 are in flight
+    double bcur[4][4], bnext[4][4], f_next[2];
+    {
+        double f0[2];
+        fetch_feat(r0, f0);
+        load_b(r0, bcur);
+        park_feat(0, f0);
+    }
+    fetch_feat(r0 + 16, f_next);  // (rows past r1 are simply not used)
     __syncthreads();
     int buf = 0;
     for (int64_t row0 = r0; row0 < r1; row0 += 16, buf ^= 1) {
         const bool more = row0 + 16 < r1;
+        double f_after[2] = {0.0, 0.0};
         if (more) {
-            stage(buf ^ 1, row0 + 16);  // the other buffer: its readers finished before the last barrier
+            park_feat(buf ^ 1, f_next);  // fetched one block ago; the buffer's readers passed the last barrier
             load_b(row0 + 16, bnext);
+            fetch_feat(row0 + 32, f_after);
         }
         const double* __restrict__ f = feat[buf];
 #pragma unroll
@@ -124,6 +152,8 @@ __global__ __launch_bounds__(512) void k_gram_mfma(const double* __restrict__ V,
             for (int st = 0; st < 4; ++st)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) bcur[st][nt] = bnext[st][nt];
+            f_next[0] = f_after[0];
+            f_next[1] = f_after[1];
         }
         __syncthreads();
     }
@@ -133,8 +163,8 @@ __global__ __launch_bounds__(512) void k_gram_mfma(const double* __restrict__ V,
     for (int x = 0; x < MTW; ++x) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int job = job_begin + (wave * MTW + x) * 16 + kq + 4 * r;
-            if (job < job_end) {
+            const int job = jb + (tile0 + x) * 16 + kq + 4 * r;
+            if (job < je) {
                 double* __restrict__ out = slab + ((int64_t)blockIdx.y * n_jobs + job) * S;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
@@ -164,25 +194,36 @@ int64_t gram_mfma_slab_doubles(int64_t N, int S, int n_jobs) {
     return (int64_t)ny * n_jobs * S;
 }
 
-template <bool VJOBS>
-static hipError_t launch_gram_mfma_range(const double* V, const double* D, const double* Rt, const double* u,
-                                         int64_t N, int S, int n_c, int n_u, const short* job_k, const short* job_l,
-                                         int n_jobs, int job_begin, int job_end, double* slab, const int* done_flag,
-                                         hipStream_t st) {
+// jobs [0, n_dense) have B = D, jobs [n_dense, count) are the "v" column (B = D * V); ny_out = slab rows per job
+hipError_t launch_gram_mfma(const double* V, const double* D, const double* Rt, const double* u, int64_t N, int S,
+                            int n_c, int n_u, GramJobTable jobs, int n_dense, double* slab, int64_t slab_doubles,
+                            const int* done_flag, int* ny_out, hipStream_t st) {
+    if (jobs.count <= 0 || n_dense < 0 || n_dense > jobs.count || n_c + n_u > kMaxK) return hipErrorInvalidValue;
     int nsx, ny;
     int64_t rpc;
     gram_mfma_geometry(N, S, &nsx, &ny, &rpc);
+    if ((int64_t)ny * jobs.count * S > slab_doubles) return hipErrorInvalidValue;
+    *ny_out = ny;
     const dim3 grid(nsx, ny), block(kGramMfmaWaves * 64);
-    while (job_begin < job_end) {
-        const int tiles = (job_end - job_begin + 15) / 16;
-        int mtw = (tiles + kGramMfmaWaves - 1) / kGramMfmaWaves;
-        if (mtw > kGramMfmaMaxTilesPerWave) mtw = kGramMfmaMaxTilesPerWave;
-        int end = job_begin + mtw * kGramMfmaWaves * 16;
-        if (end > job_end) end = job_end;
-#define DMF_CASE(M_)                                                                                               \
-    case M_:                                                                                                       \
-        hipLaunchKernelGGL((k_gram_mfma<M_, VJOBS>), grid, block, 0, st, V, D, Rt, u, N, S, n_c, n_u, job_k, job_l, \
-                           n_jobs, job_begin, end, rpc, slab, done_flag);                                          \
+    int d_begin = 0, v_begin = n_dense;
+    while (d_begin < n_dense || v_begin < jobs.count) {
+        const int tiles_d = (n_dense - d_begin + 15) / 16, tiles_v = (jobs.count - v_begin + 15) / 16;
+        // smallest tiles-per-wave that fits both kinds on 8 waves; what does not fit waits for the next launch
+        int mtw = 1;
+        while (mtw < kGramMfmaMaxTilesPerWave && (tiles_d + mtw - 1) / mtw + (tiles_v + mtw - 1) / mtw > kGramMfmaWaves)
+            ++mtw;
+        int waves_v = (tiles_v + mtw - 1) / mtw;
+        if (waves_v > kGramMfmaWaves / 2) waves_v = kGramMfmaWaves / 2;
+        int waves_d = (tiles_d + mtw - 1) / mtw;
+        if (waves_d > kGramMfmaWaves - waves_v) waves_d = kGramMfmaWaves - waves_v;
+        int d_end = d_begin + waves_d * mtw * 16, v_end = v_begin + waves_v * mtw * 16;
+        if (d_end > n_dense) d_end = n_dense;
+        if (v_end > jobs.count) v_end = jobs.count;
+        const int v_wave0 = kGramMfmaWaves - waves_v;
+#define DMF_CASE(M_)                                                                                                 \
+    case M_:                                                                                                         \
+        hipLaunchKernelGGL((k_gram_mfma<M_>), grid, block, 0, st, V, D, Rt, u, N, S, n_c, n_u, jobs.k_idx, jobs.l_idx, \
+                           jobs.count, d_begin, d_end, v_begin, v_end, v_wave0, rpc, slab, done_flag);                \
         break;
         switch (mtw) {
             DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4)
@@ -191,26 +232,10 @@ static hipError_t launch_gram_mfma_range(const double* V, const double* D, const
 #undef DMF_CASE
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        job_begin = end;
+        d_begin = d_end;
+        v_begin = v_end;
     }
     return hipSuccess;
-}
-
-// jobs [0, n_dense) have B = D, jobs [n_dense, count) are the "v" column (B = D * V); ny_out = slab rows per job
-hipError_t launch_gram_mfma(const double* V, const double* D, const double* Rt, const double* u, int64_t N, int S,
-                            int n_c, int n_u, GramJobTable jobs, int n_dense, double* slab, int64_t slab_doubles,
-                            const int* done_flag, int* ny_out, hipStream_t st) {
-    if (jobs.count <= 0 || n_c + n_u > kMaxK) return hipErrorInvalidValue;
-    int nsx, ny;
-    int64_t rpc;
-    gram_mfma_geometry(N, S, &nsx, &ny, &rpc);
-    if ((int64_t)ny * jobs.count * S > slab_doubles) return hipErrorInvalidValue;
-    *ny_out = ny;
-    hipError_t e = launch_gram_mfma_range<false>(V, D, Rt, u, N, S, n_c, n_u, jobs.k_idx, jobs.l_idx, jobs.count, 0,
-                                                 n_dense, slab, done_flag, st);
-    if (e != hipSuccess) return e;
-    return launch_gram_mfma_range<true>(V, D, Rt, u, N, S, n_c, n_u, jobs.k_idx, jobs.l_idx, jobs.count, n_dense,
-                                        jobs.count, slab, done_flag, st);
 }
 
 }  // namespace dmf

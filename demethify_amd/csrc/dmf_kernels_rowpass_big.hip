@@ -54,6 +54,7 @@ __global__ __launch_bounds__(GS == 16 ? 256 : 512) void k_u_phase_big(
     if (state->done) return;
     constexpr int NWV = GS == 16 ? 4 : 8;       // waves per workgroup
     constexpr int RPWV = 64 / GS;               // rows per wave in the B stage (NWV * RPWV = 16)
+    constexpr int kBigPrefetch = GS == 16 ? 1 : 2;  // strips in flight; measured: occupancy beats a deeper prefetch
     const int K = n_c + n_u, NP = n_u * (n_u + 1) / 2;
     const int CT = (n_u + 15) / 16, MT = (NP + 15) / 16;  // 16-row tiles of c and of M
     const BigLayout L = big_layout(S, n_c, n_u, n_iter2, GS);
@@ -133,21 +134,31 @@ __global__ __launch_bounds__(GS == 16 ? 256 : 512) void k_u_phase_big(
         // ================= M stage: this wave's tiles over all the strips =================
         const double* __restrict__ vrow = V + rowc * S;
         const double* __restrict__ drow = D + rowc * S;
-        v4d nv, nd;
+        // kBigPrefetch strips in flight per wave: one strip is only 12 MFMAs (~0.4 us) of work, far less than an
+        // HBM round trip, and with up to 200 VGPRs only two waves share a SIMD
+        v4d nv[kBigPrefetch], nd[kBigPrefetch];
+        const bool vec = (S & 3) == 0;  // a lane's four samples are then contiguous, 32-byte aligned and in range
         auto load_strip = [&](int t, v4d& e, v4d& d) {
+            if (vec) {
+                int c = 16 * t + 4 * q;
+                c = c < S ? c : S - 4;
+                const v2d v01 = *reinterpret_cast<const v2d*>(vrow + c);
+                const v2d v23 = *reinterpret_cast<const v2d*>(vrow + c + 2);
+                const v2d d01 = *reinterpret_cast<const v2d*>(drow + c);
+                const v2d d23 = *reinterpret_cast<const v2d*>(drow + c + 2);
+                e = v4d{v01.x, v01.y, v23.x, v23.y};
+                d = v4d{d01.x, d01.y, d23.x, d23.y};
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int c = 16 * t + 4 * q + r;
-                c = c < S ? c : S - 1;  // clamped: columns past S meet zero alpha
-                e[r] = vrow[c];
-                d[r] = drow[c];
+                for (int r = 0; r < 4; ++r) {
+                    int c = 16 * t + 4 * q + r;
+                    c = c < S ? c : S - 1;  // clamped: columns past S meet zero alpha
+                    e[r] = vrow[c];
+                    d[r] = drow[c];
+                }
             }
         };
-        load_strip(0, nv, nd);
-        for (int t = 0; t < nstrips; ++t) {
-            v4d e = nv;
-            const v4d d = nd;
-            if (t + 1 < nstrips) load_strip(t + 1, nv, nd);
+        auto run_strip = [&](int t, v4d e, const v4d d) {
             // E^T = V^T - alpha_known^T Rt^T: A operand row m <-> sample 16 t + 4 (m & 3) + (m >> 2), k = q
             const int s_e = 16 * t + 4 * (m16 & 3) + (m16 >> 2);
 #pragma unroll
@@ -173,6 +184,19 @@ __global__ __launch_bounds__(GS == 16 ? 256 : 512) void k_u_phase_big(
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], is_c[x] ? w[r] : d[r], acc[x], 0, 0, 0);
+                }
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < kBigPrefetch; ++i)
+            if (i < nstrips) load_strip(i, nv[i], nd[i]);
+        for (int t0 = 0; t0 < nstrips; t0 += kBigPrefetch) {
+#pragma unroll
+            for (int i = 0; i < kBigPrefetch; ++i) {
+                if (t0 + i < nstrips) {  // wave-uniform
+                    const v4d e = nv[i], d = nd[i];
+                    if (t0 + i + kBigPrefetch < nstrips) load_strip(t0 + i + kBigPrefetch, nv[i], nd[i]);
+                    run_strip(t0 + i, e, d);
                 }
             }
         }
