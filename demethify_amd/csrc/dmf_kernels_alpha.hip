@@ -401,6 +401,141 @@ __global__ __launch_bounds__(64) void k_alpha_phase_lanes(const double* __restri
     }
 }
 
+// ---- K <= 16: one sample per 16-lane DPP row, every cross-lane step on DPP (no LDS round trips) ------------
+// Same arithmetic as k_alpha_phase_lanes<16> except the summation order of G a (four interleaved chains).
+// The inner iteration of this kernel is one long dependent chain run by 64 waves at the headline size, i.e.
+// pure latency: a ds_bpermute round trip per shuffle (16 for the product, 10 sort stages, 4 scan steps) is what
+// the older kernel spends most of its 2.2 us per inner iteration on.
+template <int CTRL, bool ZERO_OOB>
+__device__ __forceinline__ double dpp16(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, ZERO_OOB);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, ZERO_OOB);
+    return __hiloint2double(hi, lo);
+}
+
+// value of lane (k ^ J) of the 16-lane row
+template <int J>
+__device__ __forceinline__ double row_xor(double x, int k) {
+    if constexpr (J == 1) return dpp16<0xB1, false>(x);       // quad_perm [1, 0, 3, 2]
+    else if constexpr (J == 2) return dpp16<0x4E, false>(x);  // quad_perm [2, 3, 0, 1]
+    else if constexpr (J == 8) return dpp16<0x128, false>(x); // row_ror:8
+    else {                                                    // J == 4: row_shl:4 for the lower half of an octet
+        const double from_above = dpp16<0x104, false>(x), from_below = dpp16<0x114, false>(x);
+        return (k & 4) ? from_below : from_above;
+    }
+}
+
+// acc += x[lane L of the row] * m   (the s_nop covers the VALU-write -> DPP-read hazard inside the asm)
+template <int L>
+__device__ __forceinline__ void fmac_rowbcast(double& acc, double x, double m) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc)
+                 : "v"(x), "v"(m), "n"(L));
+}
+
+template <int J>
+__device__ __forceinline__ void bitonic_step(double& srt, int k, int k2) {
+    const double other = row_xor<J>(srt, k);
+    const bool lower = (k & J) == 0;
+    const bool desc = (k & k2) == 0;  // final pass (k2 == 16): the whole row descending
+    srt = (lower == desc) ? fmax(srt, other) : fmin(srt, other);
+}
+
+__global__ __launch_bounds__(64) void k_alpha_phase_row16(const double* __restrict__ gb, double* __restrict__ alpha,
+                                                          double* __restrict__ alpha_prev,
+                                                          const SolverState* __restrict__ state, int S, int K,
+                                                          int n_u, int n_iter2, double* __restrict__ partials) {
+    if (state->done) return;
+    const int lane = threadIdx.x;
+    const int k = lane & 15, grp = lane >> 4, base = grp * 16;
+    const int s = blockIdx.x * 4 + grp;
+    const bool col_ok = s < S;
+    const int sc = col_ok ? s : S - 1;
+    const bool row_ok = k < K;
+    const int kc = row_ok ? k : K - 1;
+
+    double Gneg[16];  // -G_s[k][l]
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+        const int lc = l < K ? l : K - 1;
+        const int lo = kc < lc ? kc : lc, hi = kc < lc ? lc : kc;
+        const double v = gb[(int64_t)tri(lo, hi) * S + sc];
+        Gneg[l] = (row_ok && l < K) ? -v : 0.0;
+    }
+    const double bk = row_ok ? gb[(int64_t)tri(kc, K) * S + sc] : 0.0;
+    double a = row_ok ? alpha[(int64_t)kc * S + sc] : 0.0;
+    double ap = row_ok ? alpha_prev[(int64_t)kc * S + sc] : 0.0;
+
+    double a2 = state->a2, lh_prev = state->l_h_prev;
+    const double lh = state->l_h;
+    const double rank1 = (double)(k + 1);
+    for (int t = 0; t < n_iter2; ++t) {
+        double beta;
+        momentum_step(a2, lh_prev, lh, beta);
+        const double at = a + beta * (a - ap);
+        ap = a;
+        double g0 = bk, g1 = 0.0, g2 = 0.0, g3 = 0.0;  // b - G at
+        fmac_rowbcast<0>(g0, at, Gneg[0]);   fmac_rowbcast<1>(g1, at, Gneg[1]);
+        fmac_rowbcast<2>(g2, at, Gneg[2]);   fmac_rowbcast<3>(g3, at, Gneg[3]);
+        fmac_rowbcast<4>(g0, at, Gneg[4]);   fmac_rowbcast<5>(g1, at, Gneg[5]);
+        fmac_rowbcast<6>(g2, at, Gneg[6]);   fmac_rowbcast<7>(g3, at, Gneg[7]);
+        fmac_rowbcast<8>(g0, at, Gneg[8]);   fmac_rowbcast<9>(g1, at, Gneg[9]);
+        fmac_rowbcast<10>(g2, at, Gneg[10]); fmac_rowbcast<11>(g3, at, Gneg[11]);
+        fmac_rowbcast<12>(g0, at, Gneg[12]); fmac_rowbcast<13>(g1, at, Gneg[13]);
+        fmac_rowbcast<14>(g2, at, Gneg[14]); fmac_rowbcast<15>(g3, at, Gneg[15]);
+        const double g = (g0 + g1) + (g2 + g3);
+        const double x = at + g / lh;  // deconvolution.py:100: alpha_temp + (...) / l_h
+        // ---- projection onto the simplex (deconvolution.py:25-35): bitonic sort of the row, descending
+        double srt = row_ok ? x : -INFINITY;
+        bitonic_step<1>(srt, k, 2);
+        bitonic_step<2>(srt, k, 4);  bitonic_step<1>(srt, k, 4);
+        bitonic_step<4>(srt, k, 8);  bitonic_step<2>(srt, k, 8);  bitonic_step<1>(srt, k, 8);
+        bitonic_step<8>(srt, k, 16); bitonic_step<4>(srt, k, 16); bitonic_step<2>(srt, k, 16);
+        bitonic_step<1>(srt, k, 16);
+        double cum = row_ok ? srt : 0.0;  // padded lanes sort to the end (-inf) and add nothing
+        cum += dpp16<0x111, true>(cum);   // row_shr:1 .. 8, lanes without a source read 0: inclusive scan
+        cum += dpp16<0x112, true>(cum);
+        cum += dpp16<0x114, true>(cum);
+        cum += dpp16<0x118, true>(cum);
+        const double shifted = cum - 1.0;
+        const bool cond = row_ok && fma(srt, rank1, -shifted) > 0.0;
+        const unsigned long long ball = __ballot(cond);
+        const unsigned int mine = (unsigned int)((ball >> base) & 0xFFFFull);
+        // rho = last lane of the row whose condition holds (lane 0 always does for finite input)
+        const int rho = mine ? 31 - __clz((int)mine) : -1;
+        const double num = __shfl(shifted, base + (rho >= 0 ? rho : K - 1), 64);
+        const double theta = rho >= 0 ? num / (double)(rho + 1) : num / 0.0;
+        a = row_ok ? fmax(x - theta, 0.0) : 0.0;
+        lh_prev = lh;
+    }
+    if (col_ok && row_ok) {
+        alpha[(int64_t)k * S + s] = a;
+        alpha_prev[(int64_t)k * S + s] = ap;
+    }
+    // cost_s = vDv - 2 a.b + a^T G a ; ||alpha_unknown||^2
+    double ga = 0.0;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) ga = fma(-Gneg[l], __shfl(a, base + l, 64), ga);
+    double part = col_ok ? fma(a, ga, -2.0 * a * bk) : 0.0;
+    if (col_ok && k == 0) part += gb[(int64_t)tri(K, K) * S + sc];
+    double n2 = (col_ok && row_ok && k >= K - n_u) ? a * a : 0.0;
+    part = wave_sum(part);
+    n2 = wave_sum(n2);
+    if (lane == 0) {
+        partials[2 * blockIdx.x] = part;
+        partials[2 * blockIdx.x + 1] = n2;
+    }
+}
+
+static hipError_t launch_alpha_row16(const double* gb, double* alpha, double* alpha_prev, SolverState* state, int S,
+                                     int K, int n_u, int n_iter2, double* partials, hipStream_t st) {
+    const int nb = (S + 3) / 4;
+    hipLaunchKernelGGL(k_alpha_phase_row16, dim3(nb), dim3(64), 0, st, gb, alpha, alpha_prev, state, S, K, n_u,
+                       n_iter2, partials);
+    hipLaunchKernelGGL(k_finish_iteration, dim3(1), dim3(64), 0, st, partials, nb, state, n_iter2);
+    return hipGetLastError();
+}
+
 template <int G>
 static hipError_t launch_alpha_lanes_t(const double* gb, double* alpha, double* alpha_prev, SolverState* state,
                                        int S, int K, int n_u, int n_iter2, double* partials, hipStream_t st) {
@@ -416,6 +551,7 @@ hipError_t launch_alpha_phase(const double* gb, double* alpha, double* alpha_pre
                               double* partials, bool thread_per_sample, hipStream_t st) {
     const int K = n_c + n_u;
     if (!thread_per_sample) {
+        if (K <= 16) return launch_alpha_row16(gb, alpha, alpha_prev, state, S, K, n_u, n_iter2, partials, st);
         if (K <= 4) return launch_alpha_lanes_t<4>(gb, alpha, alpha_prev, state, S, K, n_u, n_iter2, partials, st);
         if (K <= 8) return launch_alpha_lanes_t<8>(gb, alpha, alpha_prev, state, S, K, n_u, n_iter2, partials, st);
         if (K <= 16) return launch_alpha_lanes_t<16>(gb, alpha, alpha_prev, state, S, K, n_u, n_iter2, partials, st);
