@@ -136,6 +136,17 @@ struct FamilyScope {
     }
 };
 
+// Device buffers come from the device's stream-ordered memory pool on the context's stream.  The pool keeps
+// what is freed (release threshold raised in dmf_context_create), so the multi-GB buffers of a problem or a
+// solver that is destroyed and re-created with the same sizes -- every bootstrap replicate does that -- are
+// handed back without a trip to the driver (hipMalloc / hipFree of 2 GB cost tens of milliseconds each).
+static hipError_t pool_alloc(dmf_context* ctx, void** p, size_t bytes) {
+    return hipMallocAsync(p, bytes, ctx->stream);
+}
+static void pool_free(dmf_context* ctx, void* p) {
+    if (p != nullptr) (void)hipFreeAsync(p, ctx->stream);
+}
+
 int import_array(dmf_context* ctx, const void* src, size_t bytes, int flags, void** dst, bool* owned) {
     if (bytes == 0) {
         *dst = nullptr;
@@ -148,11 +159,11 @@ int import_array(dmf_context* ctx, const void* src, size_t bytes, int flags, voi
         return DMF_OK;
     }
     void* d = nullptr;
-    HIP_TRY(hipMalloc(&d, bytes));
+    HIP_TRY(pool_alloc(ctx, &d, bytes));
     hipError_t e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
-        hipFree(d);
+        pool_free(ctx, d);
         return hip_fail(e, "hipMemcpyAsync(H2D)", __LINE__);
     }
     *dst = d;
@@ -172,7 +183,7 @@ int export_array(dmf_context* ctx, const void* dev_src, size_t bytes, int flags,
 int problem_finalize(dmf_problem* p) {
     dmf_context* ctx = p->ctx;
     const int64_t N = p->N, S = p->S, n_c = p->n_c;
-    HIP_TRY(hipMalloc((void**)&p->consts, 4 * sizeof(double)));
+    HIP_TRY(pool_alloc(ctx, (void**)&p->consts, 4 * sizeof(double)));
     HIP_TRY(dmf::launch_max_f64(p->D, N * S, ctx->scratch, p->consts + 2, ctx->stream));
     if (n_c > 0) {
         HIP_TRY(dmf::launch_sumsq_f64(p->Rt, N * n_c, ctx->scratch + 1024, p->consts + 1, nullptr, ctx->stream));
@@ -194,7 +205,7 @@ int problem_finalize(dmf_problem* p) {
         if (nct == n_c) {
             p->Rtp = p->Rt;
         } else {
-            HIP_TRY(hipMalloc((void**)&p->Rtp, (size_t)N * nct * sizeof(double)));
+            HIP_TRY(pool_alloc(ctx, (void**)&p->Rtp, (size_t)N * nct * sizeof(double)));
             p->own_Rtp = true;
             HIP_TRY(dmf::launch_pad_rows(p->Rt, p->Rtp, N, (int)n_c, nct, ctx->stream));
         }
@@ -215,23 +226,42 @@ int problem_finalize(dmf_problem* p) {
     short *dk = nullptr, *dl = nullptr;
     int* dd = nullptr;
     double* slab = nullptr;
-    const int64_t slab_doubles = dmf::gram_slab_doubles(N, (int)S, n_jobs);
-    HIP_TRY(hipMalloc((void**)&p->gb_known, (size_t)n_jobs * S * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&dk, n_jobs * sizeof(short)));
-    HIP_TRY(hipMalloc((void**)&dl, n_jobs * sizeof(short)));
-    HIP_TRY(hipMalloc((void**)&dd, n_jobs * sizeof(int)));
-    HIP_TRY(hipMalloc((void**)&slab, (size_t)slab_doubles * sizeof(double)));
+    // all but the last job (v, v) are sums of row-feature products against D or D * V: the matrix-core Gram
+    // kernel takes them (n_c <= 16 here: 136 + 16 jobs at most); v^T D v goes through the generic kernel alone
+    const bool mfma = n_c >= 1 && ctx->generic_level != 1 && ctx->generic_level != 2;
+    const int n_fast = mfma ? n_jobs - 1 : 0, n_dense = (int)(n_c * (n_c + 1) / 2);
+    int64_t slab_doubles = dmf::gram_slab_doubles(N, (int)S, mfma ? 1 : n_jobs);
+    if (mfma) {
+        const int64_t need = dmf::gram_mfma_slab_doubles(N, (int)S, n_fast);
+        if (need > slab_doubles) slab_doubles = need;
+    }
+    HIP_TRY(pool_alloc(ctx, (void**)&p->gb_known, (size_t)n_jobs * S * sizeof(double)));
+    HIP_TRY(pool_alloc(ctx, (void**)&dk, n_jobs * sizeof(short)));
+    HIP_TRY(pool_alloc(ctx, (void**)&dl, n_jobs * sizeof(short)));
+    HIP_TRY(pool_alloc(ctx, (void**)&dd, n_jobs * sizeof(int)));
+    HIP_TRY(pool_alloc(ctx, (void**)&slab, (size_t)slab_doubles * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(dk, hk.data(), n_jobs * sizeof(short), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(dl, hl.data(), n_jobs * sizeof(short), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(dd, hd.data(), n_jobs * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    dmf::GramJobTable jobs{dk, dl, dd, n_jobs};
-    hipError_t e = dmf::launch_gram(p->V, p->D, p->Rt, nullptr, N, (int)S, (int)n_c, 0, jobs, slab,
-                                    slab_doubles, p->gb_known, nullptr, ctx->stream);
+    hipError_t e = hipSuccess;
+    if (mfma) {
+        dmf::GramJobTable fast{dk, dl, dd, n_fast};
+        int ny = 0;
+        e = dmf::launch_gram_mfma(p->V, p->D, p->Rt, nullptr, N, (int)S, (int)n_c, 0, fast, n_dense, slab,
+                                  slab_doubles, nullptr, &ny, ctx->stream);
+        if (e == hipSuccess)
+            e = dmf::launch_gram_reduce(slab, ny, n_fast, (int)S, dd, p->gb_known, nullptr, ctx->stream);
+    }
+    if (e == hipSuccess) {
+        dmf::GramJobTable rest{dk + n_fast, dl + n_fast, dd + n_fast, n_jobs - n_fast};
+        e = dmf::launch_gram(p->V, p->D, p->Rt, nullptr, N, (int)S, (int)n_c, 0, rest, slab, slab_doubles,
+                             p->gb_known, nullptr, ctx->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    hipFree(dk);
-    hipFree(dl);
-    hipFree(dd);
-    hipFree(slab);
+    pool_free(ctx, dk);
+    pool_free(ctx, dl);
+    pool_free(ctx, dd);
+    pool_free(ctx, slab);
     if (e != hipSuccess) return hip_fail(e, "launch_gram(known block)", __LINE__);
     return DMF_OK;
 }
@@ -428,6 +458,12 @@ int dmf_context_create(int device, void* stream, dmf_context** out) {
         delete ctx;
         return hip_fail(e, "hipMalloc(scratch)", __LINE__);
     }
+    // keep freed pool memory for the next problem / solver of the same size (see pool_alloc)
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool != nullptr) {
+        uint64_t keep = UINT64_MAX;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
     *out = ctx;
     return DMF_OK;
 }
@@ -441,6 +477,8 @@ int dmf_context_destroy(dmf_context* ctx) {
         for (auto ev : c.stop) hipEventDestroy(ev);
     }
     hipFree(ctx->scratch);
+    hipMemPool_t pool = nullptr;  // hand the cached buffers back to the driver
+    if (hipDeviceGetDefaultMemPool(&pool, ctx->device) == hipSuccess && pool != nullptr) (void)hipMemPoolTrimTo(pool, 0);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return DMF_OK;
@@ -513,13 +551,13 @@ int dmf_problem_create(dmf_context* ctx, int64_t N, int64_t S, int64_t n_c, cons
             bool own_raw = false;
             st = import_array(ctx, counts, (size_t)N * S * sizeof(long long), flags, &raw, &own_raw);
             if (st == DMF_OK) {
-                hipError_t e = hipMalloc((void**)&p->D, (size_t)N * S * sizeof(double));
+                hipError_t e = pool_alloc(ctx, (void**)&p->D, (size_t)N * S * sizeof(double));
                 if (e == hipSuccess) {
                     p->own_D = true;
                     e = dmf::launch_convert_counts((const long long*)raw, p->D, N * S, ctx->stream);
                 }
                 if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-                if (own_raw) hipFree(raw);
+                if (own_raw) pool_free(ctx, raw);
                 if (e != hipSuccess) st = hip_fail(e, "count conversion", __LINE__);
             }
         }
@@ -550,20 +588,20 @@ int dmf_problem_gather(dmf_context* ctx, const dmf_problem* src, const int64_t* 
     p->n_c = src->n_c;
     long long* d_idx = nullptr;
     int st = DMF_OK;
-    hipError_t e = hipMalloc((void**)&d_idx, (size_t)n_idx * sizeof(long long));
+    hipError_t e = pool_alloc(ctx, (void**)&d_idx, (size_t)n_idx * sizeof(long long));
     if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, (size_t)n_idx * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->V, (size_t)n_idx * p->S * sizeof(double));
-    if (e == hipSuccess) p->own_V = true, e = hipMalloc((void**)&p->D, (size_t)n_idx * p->S * sizeof(double));
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&p->V, (size_t)n_idx * p->S * sizeof(double));
+    if (e == hipSuccess) p->own_V = true, e = pool_alloc(ctx, (void**)&p->D, (size_t)n_idx * p->S * sizeof(double));
     if (e == hipSuccess) p->own_D = true;
     if (e == hipSuccess && p->n_c > 0) {
-        e = hipMalloc((void**)&p->Rt, (size_t)n_idx * p->n_c * sizeof(double));
+        e = pool_alloc(ctx, (void**)&p->Rt, (size_t)n_idx * p->n_c * sizeof(double));
         if (e == hipSuccess) p->own_Rt = true;
     }
     if (e == hipSuccess) e = dmf::launch_gather_rows(src->V, p->V, d_idx, n_idx, p->S, ctx->stream);
     if (e == hipSuccess) e = dmf::launch_gather_rows(src->D, p->D, d_idx, n_idx, p->S, ctx->stream);
     if (e == hipSuccess && p->n_c > 0) e = dmf::launch_gather_rows(src->Rt, p->Rt, d_idx, n_idx, p->n_c, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    hipFree(d_idx);
+    pool_free(ctx, d_idx);
     if (e != hipSuccess) st = hip_fail(e, "row gather", __LINE__);
     if (st == DMF_OK) st = problem_finalize(p);
     if (st != DMF_OK) {
@@ -576,13 +614,14 @@ int dmf_problem_gather(dmf_context* ctx, const dmf_problem* src, const int64_t* 
 
 int dmf_problem_destroy(dmf_problem* p) {
     if (p == nullptr) return DMF_OK;
+    dmf_context* ctx = p->ctx;
     hipSetDevice(p->ctx->device);
-    if (p->own_V) hipFree(p->V);
-    if (p->own_D) hipFree(p->D);
-    if (p->own_Rt) hipFree(p->Rt);
-    if (p->own_Rtp) hipFree(p->Rtp);
-    hipFree(p->consts);
-    hipFree(p->gb_known);
+    if (p->own_V) pool_free(ctx, p->V);
+    if (p->own_D) pool_free(ctx, p->D);
+    if (p->own_Rt) pool_free(ctx, p->Rt);
+    if (p->own_Rtp) pool_free(ctx, p->Rtp);
+    pool_free(ctx, p->consts);
+    pool_free(ctx, p->gb_known);
     delete p;
     return DMF_OK;
 }
@@ -654,20 +693,20 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     const size_t un = (size_t)N * n_u * sizeof(double), an = (size_t)K * S * sizeof(double);
     const size_t gbn = (size_t)(K + 1) * (K + 2) / 2 * S * sizeof(double);
     const int nb_alpha = (int)((S + 63) / 64);
-    hipError_t e = hipMalloc((void**)&s->u, un);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->u_prev, un);
-    if (e == hipSuccess && s->u_path == 2) e = hipMalloc((void**)&s->u_next, un);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->alpha, an);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->alpha_prev, an);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->gb, gbn);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->slab, (size_t)s->slab_doubles * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->partials, (size_t)2 * (nb_alpha + S) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->u2_partials, 1024 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->state, sizeof(SolverState));
+    hipError_t e = pool_alloc(ctx, (void**)&s->u, un);
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->u_prev, un);
+    if (e == hipSuccess && s->u_path == 2) e = pool_alloc(ctx, (void**)&s->u_next, un);
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->alpha, an);
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->alpha_prev, an);
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->gb, gbn);
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->slab, (size_t)s->slab_doubles * sizeof(double));
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->partials, (size_t)2 * (nb_alpha + S) * sizeof(double));
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->u2_partials, 1024 * sizeof(double));
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->state, sizeof(SolverState));
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_state, sizeof(SolverState));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->job_k, s->n_jobs * sizeof(short));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->job_l, s->n_jobs * sizeof(short));
-    if (e == hipSuccess) e = hipMalloc((void**)&s->job_dst, s->n_jobs * sizeof(int));
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->job_k, s->n_jobs * sizeof(short));
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->job_l, s->n_jobs * sizeof(short));
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->job_dst, s->n_jobs * sizeof(int));
     const hipMemcpyKind in_kind = (flags & DMF_PTR_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (e == hipSuccess) e = hipMemsetAsync(s->state, 0, sizeof(SolverState), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->gb, 0, gbn, ctx->stream);
@@ -726,7 +765,7 @@ int dmf_solver_set_purity(dmf_solver* s, const double* purity, int flags) {
     DMF_TRY(check_ctx(ctx));
     if (s->mode != DMF_MODE_PARTIAL) return DMF_ERR_BAD_ARG;
     const size_t bytes = (size_t)s->p->S * sizeof(double);
-    if (s->purity == nullptr) HIP_TRY(hipMalloc((void**)&s->purity, bytes));
+    if (s->purity == nullptr) HIP_TRY(pool_alloc(ctx, (void**)&s->purity, bytes));
     const hipMemcpyKind kind = (flags & DMF_PTR_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     HIP_TRY(hipMemcpyAsync(s->purity, purity, bytes, kind, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -749,23 +788,24 @@ int dmf_solver_get(dmf_solver* s, int flags, double* out_u, double* out_alpha, d
 
 int dmf_solver_destroy(dmf_solver* s) {
     if (s == nullptr) return DMF_OK;
+    dmf_context* ctx = s->ctx;
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
-    hipFree(s->u);
-    hipFree(s->u_prev);
-    hipFree(s->u_next);
-    hipFree(s->alpha);
-    hipFree(s->alpha_prev);
-    hipFree(s->gb);
-    hipFree(s->slab);
-    hipFree(s->partials);
-    hipFree(s->u2_partials);
-    hipFree(s->purity);
-    hipFree(s->state);
+    pool_free(ctx, s->u);
+    pool_free(ctx, s->u_prev);
+    pool_free(ctx, s->u_next);
+    pool_free(ctx, s->alpha);
+    pool_free(ctx, s->alpha_prev);
+    pool_free(ctx, s->gb);
+    pool_free(ctx, s->slab);
+    pool_free(ctx, s->partials);
+    pool_free(ctx, s->u2_partials);
+    pool_free(ctx, s->purity);
+    pool_free(ctx, s->state);
     if (s->h_state) hipHostFree(s->h_state);
-    hipFree(s->job_k);
-    hipFree(s->job_l);
-    hipFree(s->job_dst);
+    pool_free(ctx, s->job_k);
+    pool_free(ctx, s->job_l);
+    pool_free(ctx, s->job_dst);
     delete s;
     return DMF_OK;
 }
@@ -794,7 +834,7 @@ int dmf_cost(dmf_context* ctx, const dmf_problem* p, const double* u, int64_t n_
     int st = import_array(ctx, u, (size_t)p->N * n_u * sizeof(double), flags, (void**)&du, &own_u);
     if (st == DMF_OK) st = import_array(ctx, alpha, (size_t)K * p->S * sizeof(double), flags, (void**)&da, &own_a);
     if (st == DMF_OK) {
-        hipError_t e = hipMalloc((void**)&dout, sizeof(double));
+        hipError_t e = pool_alloc(ctx, (void**)&dout, sizeof(double));
         if (e == hipSuccess) {
             FamilyScope scope(ctx, DMF_KERNEL_COST);
             e = dmf::launch_cost(p->V, p->D, p->Rt, du, da, p->N, (int)p->S, (int)p->n_c, (int)n_u,
@@ -804,9 +844,9 @@ int dmf_cost(dmf_context* ctx, const dmf_problem* p, const double* u, int64_t n_
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) st = hip_fail(e, "cost", __LINE__);
     }
-    if (own_u) hipFree(du);
-    if (own_a) hipFree(da);
-    hipFree(dout);
+    if (own_u) pool_free(ctx, du);
+    if (own_a) pool_free(ctx, da);
+    pool_free(ctx, dout);
     return st;
 }
 
@@ -822,15 +862,15 @@ int dmf_project_simplex(dmf_context* ctx, const double* X, int64_t K, int64_t S,
     if (st == DMF_OK) {
         hipError_t e = hipSuccess;
         if (flags & DMF_PTR_DEVICE) dout = out;
-        else e = hipMalloc((void**)&dout, bytes);
+        else e = pool_alloc(ctx, (void**)&dout, bytes);
         if (e == hipSuccess) e = dmf::launch_project_simplex(dx, dout, (int)K, (int)S, z, ctx->stream);
         if (e == hipSuccess && !(flags & DMF_PTR_DEVICE))
             e = hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) st = hip_fail(e, "project_simplex", __LINE__);
-        if (!(flags & DMF_PTR_DEVICE)) hipFree(dout);
+        if (!(flags & DMF_PTR_DEVICE)) pool_free(ctx, dout);
     }
-    if (own_x) hipFree(dx);
+    if (own_x) pool_free(ctx, dx);
     return st;
 }
 
@@ -870,7 +910,7 @@ int dmf_percentile_axis0(dmf_context* ctx, const double* x, int64_t n, int64_t m
     if (st == DMF_OK) {
         hipError_t e = hipSuccess;
         if (flags & DMF_PTR_DEVICE) dout = out;
-        else e = hipMalloc((void**)&dout, out_bytes);
+        else e = pool_alloc(ctx, (void**)&dout, out_bytes);
         for (int64_t i = 0; i < n_q && e == hipSuccess; i += 2) {
             const dmf::PercentilePlan p0 = percentile_plan(n, q[i]);
             const bool two = i + 1 < n_q;
@@ -882,9 +922,9 @@ int dmf_percentile_axis0(dmf_context* ctx, const double* x, int64_t n, int64_t m
             e = hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) st = hip_fail(e, "percentile_axis0", __LINE__);
-        if (!(flags & DMF_PTR_DEVICE)) hipFree(dout);
+        if (!(flags & DMF_PTR_DEVICE)) pool_free(ctx, dout);
     }
-    if (own_x) hipFree(dx);
+    if (own_x) pool_free(ctx, dx);
     return st;
 }
 
