@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -78,7 +79,10 @@ struct dmf_solver {
     int u_path = 0;         // 0 MFMA, 1 Gram-form VALU, 2 schedule-faithful direct steps
     bool use_gram_spec = false;
     bool use_gram_mfma = false;
-    bool use_u_big = false;      // 9 <= n_u <= 26: matrix-core u phase with M_i in LDS  // shapes beyond the lane-per-sample kernel's registers: MFMA Gram
+    bool use_u_big = false;      // 9 <= n_u <= 26: matrix-core u phase with M_i in LDS
+    double* cm = nullptr;        // split u phase (many inner steps): per-row c_i / M_i, allocated on first use
+    double* beta_tab = nullptr;  //   and the momentum coefficients of the inner steps
+    int64_t beta_cap = 0;  // shapes beyond the lane-per-sample kernel's registers: MFMA Gram
     bool use_fused = false;
     double* purity = nullptr;  // S per-sample known-block masses: set => Frank-Wolfe alpha phase
     double* u2_partials = nullptr;
@@ -140,11 +144,25 @@ struct FamilyScope {
 // what is freed (release threshold raised in dmf_context_create), so the multi-GB buffers of a problem or a
 // solver that is destroyed and re-created with the same sizes -- every bootstrap replicate does that -- are
 // handed back without a trip to the driver (hipMalloc / hipFree of 2 GB cost tens of milliseconds each).
+static bool pool_enabled() {  // DEMETHIFY_NO_POOL=1: plain hipMalloc / hipFree (debugging aid)
+    static const bool on = [] {
+        const char* v = getenv("DEMETHIFY_NO_POOL");
+        return !(v != nullptr && v[0] == '1');
+    }();
+    return on;
+}
 static hipError_t pool_alloc(dmf_context* ctx, void** p, size_t bytes) {
+    if (!pool_enabled()) return hipMalloc(p, bytes);
     return hipMallocAsync(p, bytes, ctx->stream);
 }
 static void pool_free(dmf_context* ctx, void* p) {
-    if (p != nullptr) (void)hipFreeAsync(p, ctx->stream);
+    if (p == nullptr) return;
+    if (!pool_enabled()) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(p);
+    } else {
+        (void)hipFreeAsync(p, ctx->stream);
+    }
 }
 
 int import_array(dmf_context* ctx, const void* src, size_t bytes, int flags, void** dst, bool* owned) {
@@ -272,6 +290,8 @@ int check_ctx(dmf_context* ctx) {
     return DMF_OK;
 }
 
+constexpr int kSplitInnerSteps = 50;  // beyond this the unfused / split u phase beats the fused kernel
+
 int enqueue_u_phase(dmf_solver* s, int n_iter2) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
@@ -279,6 +299,20 @@ int enqueue_u_phase(dmf_solver* s, int n_iter2) {
     if (s->use_u_big && dmf::u_phase_big_supported((int)p->S, (int)p->n_c, (int)s->n_u, n_iter2)) {
         HIP_TRY(dmf::launch_u_phase_big(p->V, p->D, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, (int)p->S,
                                         (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
+        return DMF_OK;
+    }
+    if (s->u_path == 0 && n_iter2 > kSplitInnerSteps && n_iter2 <= 6144) {
+        // many inner steps: one wave per workgroup running them is the bottleneck (see enqueue_outer_iteration)
+        if (s->cm == nullptr)
+            HIP_TRY(pool_alloc(ctx, (void**)&s->cm, (size_t)dmf::u_phase_split_cm_doubles(p->N, (int)s->n_u) * sizeof(double)));
+        if (s->beta_cap < n_iter2) {
+            pool_free(ctx, s->beta_tab);
+            s->beta_tab = nullptr;
+            HIP_TRY(pool_alloc(ctx, (void**)&s->beta_tab, (size_t)n_iter2 * sizeof(double)));
+            s->beta_cap = n_iter2;
+        }
+        HIP_TRY(dmf::launch_u_phase_split(p->V, p->D, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, (int)p->S,
+                                          (int)p->n_c, (int)s->n_u, n_iter2, s->mode, s->cm, s->beta_tab, ctx->stream));
         return DMF_OK;
     }
     if (s->u_path == 0) {
@@ -346,7 +380,11 @@ int enqueue_alpha_phase(dmf_solver* s, int n_iter2) {
 int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
-    if (s->use_fused) {
+    // With many inner steps the row-local iterations (one wave per workgroup in the fused kernel) dominate and
+    // the unfused u-phase kernel, which keeps three workgroups per CU busy, wins: measured at the headline size
+    // with n_iter2 = 500 (the CLI default under --purity) 18.5 ms fused against 7.6 + 1.2 ms; the estimated
+    // break-even is around 50 inner steps.
+    if (s->use_fused && n_iter2 <= kSplitInnerSteps) {
         // The fused kernel takes whole 16-row blocks; a ragged tail (< 16 rows) goes through the unfused
         // pair on offset pointers and contributes extra slab rows and one more ||u||^2 share.
         const int64_t n_full = p->N - (p->N & 15), n_tail = p->N - n_full;
@@ -794,6 +832,8 @@ int dmf_solver_destroy(dmf_solver* s) {
     pool_free(ctx, s->u);
     pool_free(ctx, s->u_prev);
     pool_free(ctx, s->u_next);
+    pool_free(ctx, s->cm);
+    pool_free(ctx, s->beta_tab);
     pool_free(ctx, s->alpha);
     pool_free(ctx, s->alpha_prev);
     pool_free(ctx, s->gb);

@@ -132,6 +132,13 @@ hipError_t launch_scatter_known_block(const double* gb_known, double* gb, int n_
 hipError_t launch_init_state(SolverState* state, const double* consts, const double* alpha,
                              int S, int n_c, int n_u, hipStream_t st);
 
+// the same u phase in two launches for many inner steps: c_i / M_i per row to `cm`, then inner iterations with
+// every lane busy; cm holds u_phase_split_cm_doubles(N, n_u) doubles, beta n_iter2 doubles (<= 6144)
+int64_t u_phase_split_cm_doubles(int64_t N, int n_u);
+hipError_t launch_u_phase_split(const double* V, const double* D, const double* Rtp, const double* alpha, double* u,
+                                double* u_prev, const SolverState* state, int64_t N, int S, int n_c, int n_u,
+                                int n_iter2, int mode, double* cm, double* beta, hipStream_t st);
+
 // u phase for 9 <= n_u <= 26 unknown types on the matrix cores (dmf_kernels_rowpass_big.hip); Rtp = padded R_trunc
 bool u_phase_big_supported(int S, int n_c, int n_u, int n_iter2);
 hipError_t launch_u_phase_big(const double* V, const double* D, const double* Rtp, const double* alpha, double* u,

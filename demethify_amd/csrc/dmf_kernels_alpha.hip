@@ -635,10 +635,103 @@ __global__ __launch_bounds__(64) void k_alpha_frank_wolfe(const double* __restri
     }
 }
 
+// K <= 16: one sample per 16-lane DPP row, as k_alpha_phase_row16 (the thread-per-sample kernel above keeps a[]
+// and grad[] in scratch and needs ~40 us per Frank-Wolfe iteration; the CLI default with --purity is 500 of them
+// per outer iteration).  Lane k owns row k of G_s; both block-wise argmins are butterfly reductions on DPP
+// moves, lowest index first among equal minima (np.argmin).
+template <int J>
+__device__ __forceinline__ void argmin_step(double& v, int& idx, int k) {
+    const double ov = row_xor<J>(v, k);
+    int oi;
+    if constexpr (J == 1) oi = __builtin_amdgcn_update_dpp(0, idx, 0xB1, 0xF, 0xF, false);
+    else if constexpr (J == 2) oi = __builtin_amdgcn_update_dpp(0, idx, 0x4E, 0xF, 0xF, false);
+    else if constexpr (J == 8) oi = __builtin_amdgcn_update_dpp(0, idx, 0x128, 0xF, 0xF, false);
+    else {
+        const int up = __builtin_amdgcn_update_dpp(0, idx, 0x104, 0xF, 0xF, false);
+        const int dn = __builtin_amdgcn_update_dpp(0, idx, 0x114, 0xF, 0xF, false);
+        oi = (k & 4) ? dn : up;
+    }
+    const bool take = ov < v || (ov == v && oi < idx);
+    v = take ? ov : v;
+    idx = take ? oi : idx;
+}
+
+__global__ __launch_bounds__(64) void k_alpha_frank_wolfe_row16(const double* __restrict__ gb,
+                                                                double* __restrict__ alpha,
+                                                                const double* __restrict__ purity,
+                                                                const SolverState* __restrict__ state, int S, int K,
+                                                                int n_u, int max_iter, double* __restrict__ partials) {
+    if (state->done) return;
+    const int lane = threadIdx.x;
+    const int k = lane & 15, grp = lane >> 4, base = grp * 16;
+    const int s = blockIdx.x * 4 + grp;
+    const bool col_ok = s < S;
+    const int sc = col_ok ? s : S - 1;
+    const bool row_ok = k < K;
+    const int kc = row_ok ? k : K - 1;
+    const int n_c = K - n_u;
+    const bool known = k < n_c, unknown = row_ok && !known;
+
+    double Grow[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+        const int lc = l < K ? l : K - 1;
+        const int lo = kc < lc ? kc : lc, hi = kc < lc ? lc : kc;
+        const double v = gb[(int64_t)tri(lo, hi) * S + sc];
+        Grow[l] = (row_ok && l < K) ? v : 0.0;
+    }
+    const double bk = row_ok ? gb[(int64_t)tri(kc, K) * S + sc] : 0.0;
+    const double pur = purity[sc];
+    const double mass = known ? pur : 1.0 - pur;  // what this lane's vertex would put on row k
+    double a = row_ok ? alpha[(int64_t)kc * S + sc] : 0.0;
+
+    for (int it = 0; it < max_iter; ++it) {
+        double g0 = -bk, g1 = 0.0, g2 = 0.0, g3 = 0.0;  // grad = G a - b (= -R^T (d * (v - R a)))
+        fmac_rowbcast<0>(g0, a, Grow[0]);   fmac_rowbcast<1>(g1, a, Grow[1]);
+        fmac_rowbcast<2>(g2, a, Grow[2]);   fmac_rowbcast<3>(g3, a, Grow[3]);
+        fmac_rowbcast<4>(g0, a, Grow[4]);   fmac_rowbcast<5>(g1, a, Grow[5]);
+        fmac_rowbcast<6>(g2, a, Grow[6]);   fmac_rowbcast<7>(g3, a, Grow[7]);
+        fmac_rowbcast<8>(g0, a, Grow[8]);   fmac_rowbcast<9>(g1, a, Grow[9]);
+        fmac_rowbcast<10>(g2, a, Grow[10]); fmac_rowbcast<11>(g3, a, Grow[11]);
+        fmac_rowbcast<12>(g0, a, Grow[12]); fmac_rowbcast<13>(g1, a, Grow[13]);
+        fmac_rowbcast<14>(g2, a, Grow[14]); fmac_rowbcast<15>(g3, a, Grow[15]);
+        const double grad = (g0 + g1) + (g2 + g3);
+        double v1 = known ? grad : INFINITY, v2 = unknown ? grad : INFINITY;
+        int i1 = k, i2 = k;
+        argmin_step<1>(v1, i1, k); argmin_step<2>(v1, i1, k); argmin_step<4>(v1, i1, k); argmin_step<8>(v1, i1, k);
+        argmin_step<1>(v2, i2, k); argmin_step<2>(v2, i2, k); argmin_step<4>(v2, i2, k); argmin_step<8>(v2, i2, k);
+        const double gamma = 2.0 / (double)(it + 2);
+        const bool at_vertex = (known && k == i1) || (unknown && k == i2);
+        const double vertex = at_vertex ? mass : 0.0;
+        a = (1.0 - gamma) * a + gamma * vertex;
+    }
+    if (col_ok && row_ok) alpha[(int64_t)k * S + s] = a;
+    // cost_s = vDv - 2 a.b + a^T G a ; ||alpha_unknown||^2
+    double ga = 0.0;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) ga = fma(Grow[l], __shfl(a, base + l, 64), ga);
+    double part = col_ok ? fma(a, ga, -2.0 * a * bk) : 0.0;
+    if (col_ok && k == 0) part += gb[(int64_t)tri(K, K) * S + sc];
+    double n2 = (col_ok && unknown) ? a * a : 0.0;
+    part = wave_sum(part);
+    n2 = wave_sum(n2);
+    if (lane == 0) {
+        partials[2 * blockIdx.x] = part;
+        partials[2 * blockIdx.x + 1] = n2;
+    }
+}
+
 hipError_t launch_alpha_frank_wolfe(const double* gb, double* alpha, const double* purity, SolverState* state,
                                     int S, int n_c, int n_u, int max_iter, double* partials, hipStream_t st) {
     const int K = n_c + n_u;
     if (K > kMaxK) return hipErrorInvalidValue;
+    if (K <= 16 && n_c >= 1) {
+        const int nb4 = (S + 3) / 4;
+        hipLaunchKernelGGL(k_alpha_frank_wolfe_row16, dim3(nb4), dim3(64), 0, st, gb, alpha, purity, state, S, K, n_u,
+                           max_iter, partials);
+        hipLaunchKernelGGL(k_finish_iteration, dim3(1), dim3(64), 0, st, partials, nb4, state, max_iter);
+        return hipGetLastError();
+    }
     const int nb = (S + 63) / 64;
     hipLaunchKernelGGL(k_alpha_frank_wolfe, dim3(nb), dim3(64), 0, st, gb, alpha, purity, state, S, K, n_u, max_iter,
                        partials);

@@ -57,7 +57,11 @@ template <int NKC, int NU, bool VEC>
 __global__ __launch_bounds__(512) void k_u_phase_mfma(
     const double* __restrict__ V, const double* __restrict__ D, const double* __restrict__ Rt,
     const double* __restrict__ alpha, double* __restrict__ u, double* __restrict__ u_prev,
-    const SolverState* __restrict__ state, int64_t N, int S, int n_c, int n_iter2, int mode) {
+    const SolverState* __restrict__ state, int64_t N, int S, int n_c, int n_iter2, int mode,
+    double* __restrict__ cm_out) {
+    // cm_out != nullptr: "split" mode for many inner steps -- the per-row c_i / M_i go to cm_out[row][NU + NP]
+    // and k_u_inner_rows runs the inner iterations with every lane of the chip busy, instead of one wave per
+    // workgroup doing them here while the others wait.
     constexpr int NP = NU * (NU + 1) / 2;
     constexpr int NMT = (NP + 15) / 16;  // 16-row tiles of the pair matrix
     constexpr int NV = NU + NP;
@@ -70,10 +74,10 @@ __global__ __launch_bounds__(512) void k_u_phase_mfma(
     const int m16 = lane & 15, q = lane >> 4;
     const double* __restrict__ A2 = alpha + (int64_t)n_c * S;
     double* __restrict__ beta_tab = lds_dyn;
-    double* __restrict__ red = lds_dyn + ((n_iter2 + 1) & ~1);
+    double* __restrict__ red = lds_dyn + (cm_out ? 0 : ((n_iter2 + 1) & ~1));
 
     // momentum coefficients of the n_iter2 inner steps (deconvolution.py:83-85): same for every row
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && cm_out == nullptr) {
         double a1 = state->a1, lw_prev = state->l_w_prev;
         const double lw = state->l_w;
         for (int t2 = 0; t2 < n_iter2; ++t2) {
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(512) void k_u_phase_mfma(
         // the wave that will run this block's inner iterations fetches its u / u_ now (first pass)
         constexpr int RPW = 64 / NU;  // rows per pass of the inner-iteration phase
         const int rl = lane / NU, j = lane - rl * NU;
-        const bool my_turn = wave == it % NW;
+        const bool my_turn = cm_out == nullptr && wave == it % NW;
         const bool ok0 = rl < RPW && rl < 16 && row0 + rl < N;
         double uu0 = 0.0, up0 = 0.0;
         if (my_turn) {
@@ -227,6 +231,15 @@ __global__ __launch_bounds__(512) void k_u_phase_mfma(
         }
         __syncthreads();
 
+        if (cm_out != nullptr) {  // split mode: fixed-order sum over the waves, one (value, row) per thread
+            const double* __restrict__ all = red + ((size_t)(it & 1) * NW * NV) * 16;
+            for (int e = threadIdx.x; e < NV * 16; e += blockDim.x) {
+                const int v = e >> 4, r = e & 15;
+                double tot = 0.0;
+                for (int w = 0; w < NW; ++w) tot += all[((size_t)w * NV + v) * 16 + r];
+                if (row0 + r < N) cm_out[(row0 + r) * NV + v] = tot;
+            }
+        }
         // ---- row-local inner iterations by one wave (round robin), lane = (row, unknown j)
         if (my_turn) {
             const double* __restrict__ all = red + ((size_t)(it & 1) * NW * NV) * 16;
@@ -274,11 +287,12 @@ bool u_phase_mfma_supported(int S, int n_c, int n_u) {
 template <int NKC, int NU>
 static hipError_t launch_u_mfma_t(const double* V, const double* D, const double* Rt, const double* alpha,
                                   double* u, double* u_prev, const SolverState* state, int64_t N, int S,
-                                  int n_c, int n_iter2, int mode, hipStream_t st) {
+                                  int n_c, int n_iter2, int mode, double* cm_out, hipStream_t st) {
     constexpr int NV = NU + NU * (NU + 1) / 2;
     const int nstrips = (S + 15) / 16;
     const int NW = (nstrips + kStripsPerWave - 1) / kStripsPerWave;
-    const size_t lds = ((size_t)((n_iter2 + 1) & ~1) + (size_t)2 * NW * NV * 16) * sizeof(double);
+    // (split mode keeps no momentum table in LDS)
+    const size_t lds = ((size_t)(cm_out ? 0 : ((n_iter2 + 1) & ~1)) + (size_t)2 * NW * NV * 16) * sizeof(double);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     const bool vec = (S & 3) == 0;
     if (lds > 48 * 1024) {
@@ -292,22 +306,36 @@ static hipError_t launch_u_mfma_t(const double* V, const double* D, const double
     const int64_t grid = nblk < 768 ? nblk : 768;
     if (vec)
         hipLaunchKernelGGL((k_u_phase_mfma<NKC, NU, true>), dim3((unsigned)grid), dim3(NW * 64), lds, st, V, D, Rt,
-                           alpha, u, u_prev, state, N, S, n_c, n_iter2, mode);
+                           alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out);
     else
         hipLaunchKernelGGL((k_u_phase_mfma<NKC, NU, false>), dim3((unsigned)grid), dim3(NW * 64), lds, st, V, D, Rt,
-                           alpha, u, u_prev, state, N, S, n_c, n_iter2, mode);
+                           alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out);
     return hipGetLastError();
 }
 
 template <int NKC>
 static hipError_t launch_u_mfma_nkc(int n_u, const double* V, const double* D, const double* Rt,
                                     const double* alpha, double* u, double* u_prev, const SolverState* state,
-                                    int64_t N, int S, int n_c, int n_iter2, int mode, hipStream_t st) {
+                                    int64_t N, int S, int n_c, int n_iter2, int mode, double* cm_out,
+                                    hipStream_t st) {
     switch (n_u) {
 #define DMF_CASE(NU_) \
-    case NU_: return launch_u_mfma_t<NKC, NU_>(V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, st);
+    case NU_: return launch_u_mfma_t<NKC, NU_>(V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
         DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4) DMF_CASE(5) DMF_CASE(6) DMF_CASE(7) DMF_CASE(8)
 #undef DMF_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+static hipError_t launch_u_phase_mfma_impl(const double* V, const double* D, const double* Rt, const double* alpha,
+                                           double* u, double* u_prev, const SolverState* state, int64_t N, int S,
+                                           int n_c, int n_u, int n_iter2, int mode, double* cm_out, hipStream_t st) {
+    switch ((n_c + 3) / 4) {
+        case 0: return launch_u_mfma_nkc<0>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
+        case 1: return launch_u_mfma_nkc<1>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
+        case 2: return launch_u_mfma_nkc<2>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
+        case 3: return launch_u_mfma_nkc<3>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
+        case 4: return launch_u_mfma_nkc<4>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -315,14 +343,87 @@ static hipError_t launch_u_mfma_nkc(int n_u, const double* V, const double* D, c
 hipError_t launch_u_phase_mfma(const double* V, const double* D, const double* Rt, const double* alpha,
                                double* u, double* u_prev, const SolverState* state, int64_t N, int S, int n_c,
                                int n_u, int n_iter2, int mode, hipStream_t st) {
-    switch ((n_c + 3) / 4) {
-        case 0: return launch_u_mfma_nkc<0>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, st);
-        case 1: return launch_u_mfma_nkc<1>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, st);
-        case 2: return launch_u_mfma_nkc<2>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, st);
-        case 3: return launch_u_mfma_nkc<3>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, st);
-        case 4: return launch_u_mfma_nkc<4>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, st);
+    return launch_u_phase_mfma_impl(V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_u, n_iter2, mode, nullptr, st);
+}
+
+// ---- split mode for many inner steps (the CLI default under --purity is 500): c_i / M_i per row through HBM
+// (N x (n_u + n_u (n_u + 1) / 2) doubles, small next to V and D), then the inner iterations with lane = (row, j)
+// over the whole chip.
+__global__ void k_beta_table(const SolverState* __restrict__ state, int n_iter2, double* __restrict__ beta_out) {
+    if (state->done) return;
+    double a1 = state->a1, lw_prev = state->l_w_prev;
+    const double lw = state->l_w;
+    for (int t2 = 0; t2 < n_iter2; ++t2) {  // deconvolution.py:83-85
+        double beta;
+        momentum_step(a1, lw_prev, lw, beta);
+        beta_out[t2] = beta;
+        lw_prev = lw;
+    }
+}
+
+template <int NU>
+__global__ __launch_bounds__(256) void k_u_inner_rows(const double* __restrict__ cm, const double* __restrict__ beta_g,
+                                                      double* __restrict__ u, double* __restrict__ u_prev,
+                                                      const SolverState* __restrict__ state, int64_t N, int n_iter2,
+                                                      int mode) {
+    constexpr int NP = NU * (NU + 1) / 2, NV = NU + NP;
+    constexpr int RPW = 64 / NU;  // rows per wave
+    extern __shared__ double beta_tab[];
+    if (state->done) return;
+    for (int t = threadIdx.x; t < n_iter2; t += 256) beta_tab[t] = beta_g[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rl = lane / NU, j = lane - rl * NU, lane0 = lane - j;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * RPW + rl;
+    const bool ok = rl < RPW && row < N;
+    const int64_t rowc = ok ? row : 0;
+    const double inv_lw = 1.0 / state->l_w;  // as in k_u_phase_mfma
+    const double* __restrict__ mine = cm + rowc * NV;
+    const double cj = mine[j];
+    double Mrow[NU];
+#pragma unroll
+    for (int l = 0; l < NU; ++l) Mrow[l] = mine[NU + (l <= j ? tri(l, j) : tri(j, l))];
+    const int64_t gi = rowc * NU + j;
+    double uu = u[gi], up = u_prev[gi];
+    for (int t2 = 0; t2 < n_iter2; ++t2) {  // same arithmetic as the inner loop of k_u_phase_mfma
+        const double beta = beta_tab[t2];
+        const double ut = uu + beta * (uu - up);
+        const double base = mode == 1 ? uu : ut;  // deconvolution.py:163 vs :88
+        up = uu;
+        const double g = grad_row<NU>(cj, base, Mrow, lane0);
+        uu = fmin(fmax(fma(g, inv_lw, ut), 0.0), 1.0);
+    }
+    if (ok) {
+        u[gi] = uu;
+        u_prev[gi] = up;
+    }
+}
+
+int64_t u_phase_split_cm_doubles(int64_t N, int n_u) { return N * (n_u + (int64_t)n_u * (n_u + 1) / 2); }
+
+// cm: N x (n_u + NP) doubles, beta: n_iter2 doubles (both device scratch owned by the caller)
+hipError_t launch_u_phase_split(const double* V, const double* D, const double* Rt, const double* alpha, double* u,
+                                double* u_prev, const SolverState* state, int64_t N, int S, int n_c, int n_u,
+                                int n_iter2, int mode, double* cm, double* beta, hipStream_t st) {
+    if (cm == nullptr || beta == nullptr || (size_t)n_iter2 * sizeof(double) > 48 * 1024) return hipErrorInvalidValue;
+    hipError_t e = launch_u_phase_mfma_impl(V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_u, n_iter2, mode, cm, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_beta_table, dim3(1), dim3(1), 0, st, state, n_iter2, beta);
+    const size_t lds = (size_t)n_iter2 * sizeof(double);
+#define DMF_CASE(NU_)                                                                                          \
+    case NU_: {                                                                                                \
+        const int64_t rows_per_block = 4 * (64 / NU_);                                                         \
+        const int64_t grid = (N + rows_per_block - 1) / rows_per_block;                                        \
+        hipLaunchKernelGGL((k_u_inner_rows<NU_>), dim3((unsigned)grid), dim3(256), lds, st, cm, beta, u, u_prev, \
+                           state, N, n_iter2, mode);                                                           \
+        break;                                                                                                 \
+    }
+    switch (n_u) {
+        DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4) DMF_CASE(5) DMF_CASE(6) DMF_CASE(7) DMF_CASE(8)
         default: return hipErrorInvalidValue;
     }
+#undef DMF_CASE
+    return hipGetLastError();
 }
 
 }  // namespace dmf

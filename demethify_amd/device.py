@@ -154,6 +154,8 @@ class Problem:
                 flags |= L.DMF_COUNTS_F64
             elif counts.dtype != torch.int64:
                 raise ValueError("counts must be int64 or float64")
+            # the tensors were produced on torch's stream, the library reads them on its own
+            torch.cuda.current_stream(V.device).synchronize()
             N, S = V.shape
         else:
             V = _host_f64(V, "meth_frequency")
