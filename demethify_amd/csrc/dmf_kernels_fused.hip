@@ -94,6 +94,27 @@ __device__ __forceinline__ double f_sub_clamp01(double a, double b) {
     return r;
 }
 
+// clip(a * b + c, 0, 1) in one instruction: the VOP3 clamp modifier clamps an FP result to [0, 1]
+// (np.clip(x, 0, 1) of deconvolution.py:88; a NaN would come out as 0 instead of NaN)
+__device__ __forceinline__ double f_fma_clamp01(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// clip(seed + sum_l x_l * Mn[l], 0, 1) over the NU lanes of a row group as one FMA chain whose last link clamps.
+// Under contention from the C waves of its SIMD the phase-B wave pays ~10 cycles per instruction issued,
+// dependent or not, so the instruction count (NU FMAs here against NU multiplies + NU adds for a balanced tree
+// and a separate clamp) matters more than the depth of the chain.
+template <int NU, int L = 0>
+__device__ __forceinline__ double f_step_chain(double acc, double x, const double (&Mn)[NU], int lane0) {
+    if constexpr (L == NU - 1) {
+        return f_fma_clamp01(f_group_bcast<NU, L>(x, lane0), Mn[L], acc);
+    } else {
+        return f_step_chain<NU, L + 1>(fma(f_group_bcast<NU, L>(x, lane0), Mn[L], acc), x, Mn, lane0);
+    }
+}
+
 // Team layout: a workgroup has 3 NW waves (NW = ceil(S / 64) column groups of 64 samples).
 //   A team  waves [0, NW): A wave w owns column group w for phase A (MFMA) and takes turns at phase B
 //   C team  waves [NW, 3 NW): C wave (g, h) owns column group g and rows [8h, 8h + 8) of every block
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                         }
                         cj *= inv_lw;
 #pragma unroll
-                        for (int l = 0; l < NU; ++l) Ms[l] *= inv_lw;
+                        for (int l = 0; l < NU; ++l) Ms[l] *= -inv_lw;  // the chain below adds -M x
                         const int64_t gi = ok ? (row0 + rloc) * NU + j : 0;
                         double uu = pass0 == 0 ? uu0 : u[gi];
                         double up = pass0 == 0 ? up0 : u_prev[gi];
@@ -411,7 +432,7 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                                                                          __builtin_amdgcn_readlane(b_lo, t2));
                                     const double ut = fma(beta, uu - up, uu);
                                     up = uu;
-                                    uu = f_sub_clamp01(ut + cj, f_dot_tree<NU, 0, NU>(up, Ms, lane0));
+                                    uu = f_step_chain<NU>(ut + cj, up, Ms, lane0);
                                 }
                             } else {          // deconvolution.py:88: gradient at the extrapolated point
                                 for (int t2 = 0; t2 < t_end; ++t2) {
@@ -419,7 +440,7 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                                                                          __builtin_amdgcn_readlane(b_lo, t2));
                                     const double ut = fma(beta, uu - up, uu);
                                     up = uu;
-                                    uu = f_sub_clamp01(ut + cj, f_dot_tree<NU, 0, NU>(ut, Ms, lane0));
+                                    uu = f_step_chain<NU>(ut + cj, ut, Ms, lane0);
                                 }
                             }
                         }
