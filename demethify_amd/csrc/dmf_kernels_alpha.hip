@@ -408,9 +408,15 @@ __global__ __launch_bounds__(64) void k_alpha_phase_lanes(const double* __restri
 // the older kernel spends most of its 2.2 us per inner iteration on.
 template <int CTRL, bool ZERO_OOB>
 __device__ __forceinline__ double dpp16(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, ZERO_OOB);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, ZERO_OOB);
-    return __hiloint2double(hi, lo);
+    if constexpr (ZERO_OOB) {  // lanes without a source must read 0: needs the "old" operand
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+        return __hiloint2double(hi, lo);
+    } else {  // permutations / values that are masked afterwards: no destination to initialise
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, false);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, false);
+        return __hiloint2double(hi, lo);
+    }
 }
 
 // value of lane (k ^ J) of the 16-lane row
@@ -643,12 +649,12 @@ template <int J>
 __device__ __forceinline__ void argmin_step(double& v, int& idx, int k) {
     const double ov = row_xor<J>(v, k);
     int oi;
-    if constexpr (J == 1) oi = __builtin_amdgcn_update_dpp(0, idx, 0xB1, 0xF, 0xF, false);
-    else if constexpr (J == 2) oi = __builtin_amdgcn_update_dpp(0, idx, 0x4E, 0xF, 0xF, false);
-    else if constexpr (J == 8) oi = __builtin_amdgcn_update_dpp(0, idx, 0x128, 0xF, 0xF, false);
+    if constexpr (J == 1) oi = __builtin_amdgcn_mov_dpp(idx, 0xB1, 0xF, 0xF, false);
+    else if constexpr (J == 2) oi = __builtin_amdgcn_mov_dpp(idx, 0x4E, 0xF, 0xF, false);
+    else if constexpr (J == 8) oi = __builtin_amdgcn_mov_dpp(idx, 0x128, 0xF, 0xF, false);
     else {
-        const int up = __builtin_amdgcn_update_dpp(0, idx, 0x104, 0xF, 0xF, false);
-        const int dn = __builtin_amdgcn_update_dpp(0, idx, 0x114, 0xF, 0xF, false);
+        const int up = __builtin_amdgcn_mov_dpp(idx, 0x104, 0xF, 0xF, false);
+        const int dn = __builtin_amdgcn_mov_dpp(idx, 0x114, 0xF, 0xF, false);
         oi = (k & 4) ? dn : up;
     }
     const bool take = ov < v || (ov == v && oi < idx);

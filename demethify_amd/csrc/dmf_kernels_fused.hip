@@ -61,8 +61,10 @@ constexpr int kTileBytes = kTileVBytes + 16 * kTileRowFloats * 4;  // one column
 
 template <int CTRL>
 __device__ __forceinline__ double f_dpp_quad(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    // mov_dpp, not update_dpp(0, ...): a quad permute has a source in every lane, and an "old" value would
+    // cost a v_mov per half to initialise the destination (8 extra instructions per inner step at n_u = 4)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 
@@ -427,6 +429,7 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                             const int b_lo = __double2loint(bvec), b_hi = __double2hiint(bvec);
                             const int t_end = n_iter2 - t0 < 64 ? n_iter2 - t0 : 64;
                             if (mode == 1) {  // deconvolution.py:163: gradient at the previous iterate
+#pragma unroll 2  // (u, u_) swap roles every step: unrolled by two, the copies between them disappear
                                 for (int t2 = 0; t2 < t_end; ++t2) {
                                     const double beta = __hiloint2double(__builtin_amdgcn_readlane(b_hi, t2),
                                                                          __builtin_amdgcn_readlane(b_lo, t2));
@@ -435,6 +438,7 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
                                     uu = f_step_chain<NU>(ut + cj, up, Ms, lane0);
                                 }
                             } else {          // deconvolution.py:88: gradient at the extrapolated point
+#pragma unroll 2  // (u, u_) swap roles every step: unrolled by two, the copies between them disappear
                                 for (int t2 = 0; t2 < t_end; ++t2) {
                                     const double beta = __hiloint2double(__builtin_amdgcn_readlane(b_hi, t2),
                                                                          __builtin_amdgcn_readlane(b_lo, t2));

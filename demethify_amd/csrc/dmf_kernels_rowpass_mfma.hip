@@ -29,8 +29,9 @@ constexpr int kMfmaMaxWaves = 8;   // S <= 512 on this path
 // quad permute (no LDS traffic); other group sizes go through ds_bpermute.
 template <int CTRL>
 __device__ __forceinline__ double dpp_quad(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    // (mov_dpp: every lane of a quad permute has a source, no "old" value to initialise)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 
