@@ -31,6 +31,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 #ifdef DMF_STAMPS
 #define DMF_STAMP_DECL unsigned long long st_last = dmf_stamp(), st_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define DMF_STAMP(i) { const unsigned long long st_now = dmf_stamp(); st_seg[i] += st_now - st_last; st_last = st_now; }
+#define DMF_ROW_STAMP(rr) if (r_begin == 8 * half && (rr) < 3) DMF_STAMP(5 + (rr))
 #define DMF_STAMP_FLUSH if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) stamps_out[((size_t)blockIdx.x * 16 + wave) * 8 + i_] = st_seg[i_];
 __device__ __forceinline__ unsigned long long dmf_stamp() {
     unsigned long long t;
@@ -41,6 +42,7 @@ __device__ __forceinline__ unsigned long long dmf_stamp() {
 }
 #else
 #define DMF_STAMP_DECL
+#define DMF_ROW_STAMP(rr)
 #define DMF_STAMP(i)
 #define DMF_STAMP_FLUSH
 #endif
@@ -478,6 +480,7 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
         for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
         const int sC = wcol0 + lane;  // lane = sample column
 
+        DMF_STAMP_DECL
         auto accum_rows = [&](int buf, int r_begin, int n_rows) {
             const char* __restrict__ tile = tile_of(buf);
             const double* __restrict__ tileV = reinterpret_cast<const double*>(tile);
@@ -521,10 +524,10 @@ __global__ __launch_bounds__(768) void k_rowpass_fused(
 #pragma unroll
                 for (int jj = 0; jj < NU; ++jj)
                     acc[NCT * NU + NP + jj] = fma(t[jj], v, acc[NCT * NU + NP + jj]);
+                DMF_ROW_STAMP(rr)
             }
         };
 
-        DMF_STAMP_DECL
         for (int s = 0; s <= nk; ++s) {
             int buf = 0;
             if (s >= 1) {

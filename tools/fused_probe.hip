@@ -45,6 +45,7 @@ int main(int argc, char** argv) {
         if (team == 0) printf("   %-26s %6.1f %%  (%.0f cycles per block-step)\n", "tile store (vmcnt waits)", 100 * sum[5] / tot, sum[5] / cnt / ((N / 16.0) / grid));
         printf("%s team: mean cycles per wave %.0f over the kernel\n", team == 0 ? "A" : "C", tot / cnt);
         for (int i = 0; i < 5; ++i) printf("   %-26s %6.1f %%  (%.0f cycles per block-step)\n", team == 0 ? an[i] : cn[i], 100 * sum[i] / tot, sum[i] / cnt / ((N / 16.0) / grid));
+        if (team == 1) printf("   of the rows before X: first row %.0f, second %.0f, third %.0f cycles (the rest lands in 'rows first half')\n", sum[5] / cnt / ((N / 16.0) / grid), sum[6] / cnt / ((N / 16.0) / grid), sum[7] / cnt / ((N / 16.0) / grid));
     }
     return 0;
 }
