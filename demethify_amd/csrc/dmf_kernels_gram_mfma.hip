@@ -27,7 +27,14 @@ constexpr int kGramMfmaMaxTilesPerWave = 4;  // 16 accumulators per tile: 5 and 
 
 // Waves [0, v_wave0) take the jobs [job_begin, job_end) (B = D), waves [v_wave0, 8) the "v" jobs
 // [vjob_begin, vjob_end) (B = D * V); MTW consecutive 16-job tiles per wave.
-template <int MTW>
+typedef __attribute__((address_space(1))) const void gmem_void;
+typedef __attribute__((address_space(3))) int lds_int;
+
+// DMA: S is even, so a block's 16 x 64 tile of D (and of V, if some wave owns b rows) is fetched once per
+// workgroup straight into LDS with global_load_lds_dwordx4 (one 16-B request per thread and tile, no VGPR
+// destination, a whole block ahead) and every wave reads its B operands from there; otherwise (odd S: 16-B
+// requests would straddle row ends) each wave loads its own B operands into registers, one block ahead.
+template <int MTW, bool DMA>
 __global__ __launch_bounds__(512) void k_gram_mfma(const double* __restrict__ V, const double* __restrict__ D,
                                                    const double* __restrict__ Rt, const double* __restrict__ u,
                                                    int64_t N, int S, int n_c, int n_u,
@@ -36,6 +43,8 @@ __global__ __launch_bounds__(512) void k_gram_mfma(const double* __restrict__ V,
                                                    int vjob_end, int v_wave0, int64_t rows_per_chunk,
                                                    double* __restrict__ slab, const int* __restrict__ done_flag) {
     __shared__ double feat[2][16 * (kMaxK + 1)];  // [buffer][row][feature], row stride K + 1
+    __shared__ __attribute__((aligned(16))) double dtile[DMA ? 2 : 1][DMA ? 16 * 64 : 2];
+    __shared__ __attribute__((aligned(16))) double vtile[DMA ? 2 : 1][DMA ? 16 * 64 : 2];
     if (done_flag != nullptr && *done_flag) return;
     const int K = n_c + n_u, FS = K + 1;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -111,16 +120,38 @@ __global__ __launch_bounds__(512) void k_gram_mfma(const double* __restrict__ V,
         }
     };
 
+    const bool any_v = v_wave0 < kGramMfmaWaves;  // some wave owns b rows: the V tile is needed too
+    // DMA: thread t fetches the pair of samples 2 (t % 32), + 1 of tile row t / 32 (clamped into the matrix:
+    // clamped rows meet zero features, clamped columns are computed and never stored)
+    auto fetch_tile = [&](int tb, int64_t row0) {
+        if constexpr (DMA) {
+            int64_t row = row0 + (threadIdx.x >> 5);
+            row = row < N ? row : N - 1;
+            int c = s0 + 2 * (threadIdx.x & 31);
+            c = c < S ? c : S - 2;
+            const int64_t off = row * S + c;
+            // one wave-wide request writes 64 x 16 B = 1 KB of contiguous LDS: wave w covers tile rows 2 w, 2 w + 1
+            lds_int* dst_d = (lds_int*)(&dtile[tb][0]) + (threadIdx.x >> 6) * 256;
+            __builtin_amdgcn_global_load_lds((gmem_void*)(D + off), dst_d, 16, 0, 0);
+            if (any_v) {
+                lds_int* dst_v = (lds_int*)(&vtile[tb][0]) + (threadIdx.x >> 6) * 256;
+                __builtin_amdgcn_global_load_lds((gmem_void*)(V + off), dst_v, 16, 0, 0);
+            }
+        }
+    };
+
     // software pipeline over 16-row blocks: while block i runs on the matrix cores, the D operands of block
     // i + 1 and the row features of block i + 2 are in flight
-    double bcur[4][4], bnext[4][4], f_next[2];
+    double bcur[DMA ? 1 : 4][4], bnext[DMA ? 1 : 4][4], f_next[2];
     {
         double f0[2];
         fetch_feat(r0, f0);
-        load_b(r0, bcur);
+        if constexpr (DMA) fetch_tile(0, r0);
+        else load_b(r0, bcur);
         park_feat(0, f0);
     }
     fetch_feat(r0 + 16, f_next);  // (rows past r1 are simply not used)
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
     for (int64_t row0 = r0; row0 < r1; row0 += 16, buf ^= 1) {
@@ -128,13 +159,14 @@ __global__ __launch_bounds__(512) void k_gram_mfma(const double* __restrict__ V,
         double f_after[2] = {0.0, 0.0};
         if (more) {
             park_feat(buf ^ 1, f_next);  // fetched one block ago; the buffer's readers passed the last barrier
-            load_b(row0 + 16, bnext);
+            if constexpr (DMA) fetch_tile(buf ^ 1, row0 + 16);
+            else load_b(row0 + 16, bnext);
             fetch_feat(row0 + 32, f_after);
         }
         const double* __restrict__ f = feat[buf];
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
-            double a[MTW];
+            double a[MTW], b[4];
 #pragma unroll
             for (int x = 0; x < MTW; ++x) {
                 const double fa = f[(4 * st + kq) * FS + fk[x]];
@@ -142,19 +174,33 @@ __global__ __launch_bounds__(512) void k_gram_mfma(const double* __restrict__ V,
                 a[x] = fa * fb;
             }
 #pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                if constexpr (DMA) {
+                    b[nt] = dtile[buf][(4 * st + kq) * 64 + 16 * nt + i16];
+                    if (VJOBS) b[nt] *= vtile[buf][(4 * st + kq) * 64 + 16 * nt + i16];
+                } else {
+                    b[nt] = bcur[st][nt];
+                }
+            }
+#pragma unroll
             for (int x = 0; x < MTW; ++x)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    acc[x][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], bcur[st][nt], acc[x][nt], 0, 0, 0);
+                    acc[x][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[nt], acc[x][nt], 0, 0, 0);
         }
         if (more) {
+            if constexpr (!DMA) {
 #pragma unroll
-            for (int st = 0; st < 4; ++st)
+                for (int st = 0; st < 4; ++st)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) bcur[st][nt] = bnext[st][nt];
+                    for (int nt = 0; nt < 4; ++nt) bcur[st][nt] = bnext[st][nt];
+            }
             f_next[0] = f_after[0];
             f_next[1] = f_after[1];
         }
+        // the tile fetch issued at the top of this block has landed before anyone passes the barrier (so has
+        // the feature fetch of block i + 2: both had the whole block to arrive)
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -178,7 +224,7 @@ __global__ __launch_bounds__(512) void k_gram_mfma(const double* __restrict__ V,
 
 static void gram_mfma_geometry(int64_t N, int S, int* nsx, int* ny, int64_t* rows_per_chunk) {
     *nsx = (S + 63) / 64;
-    int64_t want = 256 / (*nsx);  // one 8-wave workgroup per CU
+    int64_t want = 512 / (*nsx);  // two 8-wave workgroups per CU when the registers allow (<= 2 tiles per wave)
     if (want < 1) want = 1;
     int64_t rpc = (N + want - 1) / want;
     rpc = (rpc + 15) / 16 * 16;
@@ -205,6 +251,7 @@ hipError_t launch_gram_mfma(const double* V, const double* D, const double* Rt, 
     if ((int64_t)ny * jobs.count * S > slab_doubles) return hipErrorInvalidValue;
     *ny_out = ny;
     const dim3 grid(nsx, ny), block(kGramMfmaWaves * 64);
+    const bool dma = (S & 1) == 0 && S >= 2 && ((uintptr_t)D & 15) == 0 && ((uintptr_t)V & 15) == 0;
     int d_begin = 0, v_begin = n_dense;
     while (d_begin < n_dense || v_begin < jobs.count) {
         const int tiles_d = (n_dense - d_begin + 15) / 16, tiles_v = (jobs.count - v_begin + 15) / 16;
@@ -220,10 +267,16 @@ hipError_t launch_gram_mfma(const double* V, const double* D, const double* Rt, 
         if (d_end > n_dense) d_end = n_dense;
         if (v_end > jobs.count) v_end = jobs.count;
         const int v_wave0 = kGramMfmaWaves - waves_v;
-#define DMF_CASE(M_)                                                                                                 \
-    case M_:                                                                                                         \
-        hipLaunchKernelGGL((k_gram_mfma<M_>), grid, block, 0, st, V, D, Rt, u, N, S, n_c, n_u, jobs.k_idx, jobs.l_idx, \
-                           jobs.count, d_begin, d_end, v_begin, v_end, v_wave0, rpc, slab, done_flag);                \
+#define DMF_CASE(M_)                                                                                          \
+    case M_:                                                                                                  \
+        if (dma)                                                                                              \
+            hipLaunchKernelGGL((k_gram_mfma<M_, true>), grid, block, 0, st, V, D, Rt, u, N, S, n_c, n_u,      \
+                               jobs.k_idx, jobs.l_idx, jobs.count, d_begin, d_end, v_begin, v_end, v_wave0, \
+                               rpc, slab, done_flag);                                                         \
+        else                                                                                                  \
+            hipLaunchKernelGGL((k_gram_mfma<M_, false>), grid, block, 0, st, V, D, Rt, u, N, S, n_c, n_u,     \
+                               jobs.k_idx, jobs.l_idx, jobs.count, d_begin, d_end, v_begin, v_end, v_wave0, \
+                               rpc, slab, done_flag);                                                         \
         break;
         switch (mtw) {
             DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4)
