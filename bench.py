@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
-"""Benchmark of the solver hot path on MI355X.
+"""Benchmark of the solver hot path on MI355X: BASELINE.json's restart job.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--restarts R]
 
-A "step" is ONE OUTER ITERATION of the partial-reference solver (20 u inner updates + 20 alpha
-inner updates + 1 cost evaluation, demethify/deconvolution.py:206-221) on the headline synthetic
-workload of BASELINE.json: 1e6 CpG x 256 samples, 12 known + 4 unknown cell types, inputs already
-resident in HBM when the timed region starts.  With N > 1 (launched by torch.distributed.run, one
-process per GPU) every rank runs one random restart of the same problem (restart k = seed 1 + k,
-data replicated) and the ranks exchange one RCCL all-reduce(min) to pick the best restart: weak
-scaling, value = outer iterations of all ranks / wall time.
+The job (BASELINE.json configs[2]; reference loop demethify/demethify.py:195-203):
+R = 64 random restarts of the partial-reference solver on ONE synthetic problem, 1e6 CpG x 256 samples, 12 known + 4
+unknown cell types, V / D / R_trunc already resident in HBM on every rank when the timed region starts.  Restart k
+uses seed 1 + k and runs on rank k mod N (one process per GPU, torch.distributed, RCCL); the problem is replicated,
+nothing of the N x S data path is exchanged.  A "step" is ONE OUTER ITERATION (20 u inner updates + 20 alpha inner
+updates + 1 cost evaluation, demethify/deconvolution.py:206-221) of every restart: K steps = the job with
+--iterations K 20 --termination 0.  The timed region holds everything the job does after the data is resident:
+the host-side init of every restart (legacy MT19937 stream in the reference's order, deconvolution.py:55-56, drawn
+by a worker thread while the GPU solves the previous restart), the upload of u0 / alpha0, the solver set-up (initial
+cost, :204), the K outer iterations, the per-restart cost_f_w (demethify.py:199), ONE all-reduce(min) over the
+R-element cost vector and the broadcast of the winner's (u, alpha).  Total work is fixed as N grows: strong scaling,
+value = R * K outer iterations / wall time (max over ranks).
 
-Prints ONE JSON line on rank 0 (fields: see the driver contract; plus "roofline" and
-"cpu_baseline").
+Prints ONE JSON line on rank 0 (fields: see the driver contract; plus "roofline", "cpu_baseline" and "loop_only" =
+the rate of the K-iteration loops alone, which is what round 1 reported as value).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import queue
+import subprocess
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -28,7 +36,9 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6  # FP64 vector = FP64 matrix peak (256 CUs x 4 SIMDs x 16 FMA/clk x 2.4 GHz)
+T2 = 20                 # inner iterations (CLI default, demethify.py:64)
 WORKLOADS = {
     # name: (N, S, n_c, n_u)
     "headline_1e6x256_12+4": (1_000_000, 256, 12, 4),
@@ -37,15 +47,22 @@ WORKLOADS = {
 
 
 def algorithmic_bytes(N, S, n_c, n_u):
-    """compulsory HBM bytes of one outer iteration: read V and D once,
+    """compulsory HBM bytes of one outer iteration: read V and D once (f64 each),
     read R_trunc, read u and u_ and write u."""
     return N * S * 16 + N * 8 * (n_c + 3 * n_u)
 
 
+def algorithmic_flops(N, S, n_c, n_u, t2=T2):
+    """flops of one outer iteration in the one-pass (fused) form."""
+    return N * S * (2 * n_c + 4 * n_u + 2 * n_u * (n_u + 1) + 2 * n_c * n_u + 4) + t2 * N * (2 * n_u * n_u + 8 * n_u)
+
+
 def make_inputs_on_device(torch, dev, N, S, n_c, n_u, seed=0):
-    """Synthetic CpG x sample data, SURVEY.md section 8(d) recipe (Beta(.5,.5) profiles, Dirichlet
-    proportions, Poisson(50)+1 depth, Binomial counts); the small factors come from numpy, the two
-    N x S draws are made directly in HBM."""
+    """Synthetic CpG x sample data, SURVEY.md section 8(d) recipe (Beta(.5,.5) profiles, Dirichlet proportions,
+    Poisson(50)+1 depth, Binomial counts).  The small factors (N x K profiles, K x S proportions) come from
+    legacy numpy RandomState(seed) exactly as the recipe says; the two N x S draws (Poisson depth, Binomial
+    counts) are made directly in HBM with torch's Philox generator: same distributions, different bits than a
+    host-side legacy-numpy draw of 2.56e8 values would give."""
     rs = np.random.RandomState(seed)
     K = n_c + n_u
     Rfull = rs.beta(0.5, 0.5, size=(N, K))
@@ -62,9 +79,32 @@ def make_inputs_on_device(torch, dev, N, S, n_c, n_u, seed=0):
     return V, D.contiguous(), Rt
 
 
-def cpu_baseline(V_host, D_host, Rt_host, n_u, N_full, budget_iters=2):
-    """The oracle (numpy restatement of the reference schedule) timed on this box's host cores on a
-    bounded row sample; per-iteration time is linear in N, so the rate is scaled by sample/N."""
+def restart_init(k, N, S, n_c, n_u):
+    """init_BSSMF_md('uniform_', ..., seed=1 + k) of the reference (deconvolution.py:41,55-56): uniform N x n_u
+    first, then Dirichlet; a private RandomState(seed) yields the same stream as the global one seeded alike."""
+    rs = np.random.RandomState(1 + k)
+    u0 = rs.uniform(size=(N, n_u))
+    a0 = rs.dirichlet(np.ones(n_c + n_u), S).T
+    return u0, np.ascontiguousarray(a0)
+
+
+class InitFeeder(threading.Thread):
+    """Draws the (u0, alpha0) of this rank's restarts one ahead of the GPU (numpy's generators release the GIL)."""
+
+    def __init__(self, ks, shape):
+        super().__init__(daemon=True)
+        self.ks, self.shape = ks, shape
+        self.q = queue.Queue(maxsize=2)
+
+    def run(self):
+        for k in self.ks:
+            self.q.put((k, restart_init(k, *self.shape)))
+
+
+def cpu_baseline(V_dev, D_dev, Rt_dev, n_u, N_full, rows=(62_500, 250_000)):
+    """The oracle (numpy restatement of the reference schedule, oracle/solver.py) timed on this box's host cores:
+    ONE full outer iteration (T2 = 20) on the first `rows` CpG rows of the same synthetic problem, at two sample
+    sizes so that the linearity in N the extrapolation to N_full relies on is measured, not assumed."""
     from oracle import solver as osol
 
     try:
@@ -75,25 +115,41 @@ def cpu_baseline(V_host, D_host, Rt_host, n_u, N_full, budget_iters=2):
         blas_threads = max([int(i.get("num_threads") or 1) for i in pools if i.get("user_api") == "blas"] or [1])
     except Exception:  # pragma: no cover
         blas, blas_threads = [], 1
-    u0, R, a0 = osol.init_partial("uniform_", V_host, D_host, Rt_host, n_u, seed=1)
-    t0 = time.perf_counter()
-    osol.solve_partial(u0, R, a0, V_host, D_host, Rt_host, n_u, budget_iters, 20, 0.0,
-                       project=osol.simplex_project_columns_fast)
-    dt = time.perf_counter() - t0
-    n_s = V_host.shape[0]
-    rate_sample = budget_iters / dt
+    secs = []
+    for n_s in rows:
+        n_s = min(n_s, N_full)
+        V = V_dev[:n_s].cpu().numpy()
+        D = D_dev[:n_s].cpu().numpy().astype(np.int64)
+        Rt = Rt_dev[:n_s].cpu().numpy()
+        u0, R, a0 = osol.init_partial("uniform_", V, D, Rt, n_u, seed=1)
+        t0 = time.perf_counter()
+        osol.solve_partial(u0, R, a0, V, D, Rt, n_u, 1, T2, 0.0, project=osol.simplex_project_columns_fast)
+        secs.append(time.perf_counter() - t0)
+        del V, D, Rt, u0, R, a0
+    n_big = min(rows[-1], N_full)
+    per_row = [s / min(r, N_full) for s, r in zip(secs, rows)]
     return {
-        "value": rate_sample * n_s / N_full,
+        "value": (1.0 / secs[-1]) * n_big / N_full,
         "unit": "outer iters/s",
         # threads actually used: numpy's elementwise temporaries are single-threaded, only the skinny dgemms
         # fan out over the BLAS pool (default threading, as the reference would run)
         "cores": blas_threads,
         "host_cpus": os.cpu_count(),
         "kind": "port",
-        "sample": f"{budget_iters} outer iterations (T2=20) of oracle/solver.py on the first {n_s} of {N_full} "
-                  f"CpG rows x {V_host.shape[1]} samples, {dt:.1f} s wall; rate scaled by {n_s}/{N_full}",
+        "sample": f"1 outer iteration (T2={T2}, incl. the two cost evaluations) of oracle/solver.py on the first {n_big} of "
+                  f"{N_full} CpG rows x {V_dev.shape[1]} samples: {secs[-1]:.1f} s wall; rate scaled by {n_big}/{N_full}",
+        "linearity": {"rows": [min(r, N_full) for r in rows], "seconds_per_outer_iteration": [round(s, 2) for s in secs],
+                      "seconds_per_row_ratio_large_over_small": round(per_row[-1] / per_row[0], 3)},
         "blas": blas,
     }
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True,
+                              timeout=5).stdout.strip() or None
+    except Exception:
+        return None
 
 
 def main():
@@ -101,11 +157,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--restarts", type=int, default=64, help="restarts of the whole job (BASELINE config 3: 64)")
     ap.add_argument("--workload", default="headline_1e6x256_12+4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=40_000)
     ap.add_argument("--kernels", type=int, default=0, choices=[0, 1, 2, 3],
-                    help="kernel selection level (dmf_context_set_generic): 0 = fused row pass (default)")
+                    help="kernel selection level (dmf_context_set_generic): 0 = fastest (default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --share-gpu rehearses the N > 1 path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -132,125 +188,173 @@ def main():
             dist.init_process_group(backend="gloo")
 
     from demethify_amd import _lib as L
+    from demethify_amd import shard
     from demethify_amd.device import Context, Problem, Solver
-    from demethify_amd.shard import pick_min_cost
 
     N, S, n_c, n_u = WORKLOADS[args.workload]
     K = n_c + n_u
+    R = args.restarts
     V, D, Rt = make_inputs_on_device(torch, dev, N, S, n_c, n_u, seed=0)
     torch.cuda.synchronize()
 
     ctx = Context(local_rank)
     ctx.set_generic(args.kernels)
     problem = Problem(ctx, V, D, Rt)
-    # restart k uses seed 1 + k; init drawn on the host in the reference's order
-    rs = np.random.RandomState(1 + rank)
-    u0 = rs.uniform(size=(N, n_u))
-    a0 = rs.dirichlet(np.ones(K), S).T
-    solver = Solver(problem, u0, a0, L.DMF_MODE_PARTIAL)
 
-    solver.step(args.warmup, 20, 0.0)
+    # ---- warm-up: W untimed steps of one restart per rank (+ the collectives once, so that RCCL's lazy
+    # communicator set-up is not in the timed region)
+    u0, a0 = restart_init(rank, N, S, n_c, n_u)
+    with Solver(problem, u0, a0, L.DMF_MODE_PARTIAL) as s:
+        kernels = s.describe(T2)
+        s.step(args.warmup, T2, 0.0)
+        s.direct_cost()
+    if world > 1:
+        shard.allreduce_min_vector({rank: 0.0}, world)
+        shard.broadcast_arrays((np.zeros(8),), 0)
     ctx.synchronize()
-    # HIP events around the two families that stream V / D (the roofline kernel is one of them); the
-    # KB-sized alpha phase is timed after the timed region so that its event records do not sit in it
-    ctx.set_profiling(True, families=(L.KERNEL_ROWPASS, L.KERNEL_GRAM))
+    # HIP events around the two families that stream V / D (the roofline kernel is one of them), on the stream
+    # the kernels are launched on; the KB-sized alpha phase is timed after the job
+    ctx.set_profiling(True, families=(L.KERNEL_ROWPASS, L.KERNEL_GRAM, L.KERNEL_COST))
     ctx.reset_kernel_time()
 
+    mine = shard.my_items(R, rank, world)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    iters, _ = solver.step(args.steps, 20, 0.0)
+    # ------------------------------------------------------------------ timed region: the restart job
+    feeder = InitFeeder(mine, (N, S, n_c, n_u))
+    feeder.start()
+    best, local_costs, loop_s, iters_total = None, {}, 0.0, 0
+    for _ in mine:
+        k, (u0, a0) = feeder.q.get()
+        s = Solver(problem, u0, a0, L.DMF_MODE_PARTIAL)
+        tl = time.perf_counter()
+        it, _ = s.step(args.steps, T2, 0.0)  # returns after the last iteration's state has been read back
+        loop_s += time.perf_counter() - tl
+        iters_total += it
+        cost = s.direct_cost()               # cost_f_w per restart, demethify.py:199
+        local_costs[k] = cost
+        if best is None or cost < best[0]:   # strict '<': the first minimum wins (demethify.py:200)
+            if best is not None:
+                best[2].close()
+            best = (cost, k, s)
+        else:
+            s.close()
+    costs = shard.allreduce_min_vector(local_costs, R)  # ONE all-reduce(min), 8 R bytes
+    best_k = shard.argmin_first(costs)
+    owner = best_k % world
+    if rank == owner:
+        u_w, a_w, _, _ = best[2].get()
+        payload = (u_w, a_w)
+    else:
+        payload = (np.empty((N, n_u)), np.empty((K, S)))
+    u_w, a_w = shard.broadcast_arrays(payload, owner)
+    if best is not None:
+        best[2].close()
     ctx.synchronize()
-    if world > 1:
-        cost, _ = solver.get_cost()
-        best_rank, best_cost = pick_min_cost(cost, rank, world, dev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # ------------------------------------------------------------------ end of the timed region
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert iters == args.warmup + args.steps, (iters, args.warmup, args.steps)
+    assert iters_total == len(mine) * args.steps, (iters_total, len(mine), args.steps)
+    assert np.isfinite(costs).all() and u_w.shape == (N, n_u)
 
     fam = {name: ctx.kernel_time(i) for i, name in enumerate(L.KERNEL_FAMILIES)}
     ctx.reset_kernel_time()
-    ctx.set_profiling(True, families=(L.KERNEL_ALPHA, L.KERNEL_COST))
-    solver.step(2, 20, 0.0)  # untimed: fills in the small families of the per-family table
+    ctx.set_profiling(True, families=(L.KERNEL_ALPHA,))
+    u0, a0 = restart_init(rank, N, S, n_c, n_u)
+    with Solver(problem, u0, a0, L.DMF_MODE_PARTIAL) as s:
+        s.step(2, T2, 0.0)  # untimed: fills in the small family of the per-family table
     ctx.synchronize()
-    for i in (L.KERNEL_ALPHA, L.KERNEL_COST):
-        fam[L.KERNEL_FAMILIES[i]] = ctx.kernel_time(i)
+    fam[L.KERNEL_FAMILIES[L.KERNEL_ALPHA]] = ctx.kernel_time(L.KERNEL_ALPHA)
     ctx.set_profiling(False)
 
     if rank == 0:
         b_alg = algorithmic_bytes(N, S, n_c, n_u)
+        flops = algorithmic_flops(N, S, n_c, n_u)
         fam_ms = {k: (v[0] / max(v[1], 1), v[1]) for k, v in fam.items()}
-        # dominant kernel family of the outer iteration and its algorithmic traffic per launch
-        # With the fused row pass (--kernels 0) ONE launch of the "rowpass" family does the whole V / D
-        # stream of an outer iteration: B_alg of SURVEY.md 8(d).  The unfused pair (--kernels 3) reads V
-        # and D once per kernel.
+        # dominant kernel family of the outer iteration and its algorithmic traffic per launch.  With the fused
+        # row pass (--kernels 0) ONE launch of the "rowpass" family does the whole V / D stream of an outer
+        # iteration (1 unit = 1 outer iteration per launch): B_alg of SURVEY.md 8(d).  The unfused pair
+        # (--kernels 3) reads V and D once per kernel.
         per_launch_bytes = {
             "rowpass": N * S * 16 + N * 8 * (n_c + 3 * n_u),   # V, D, R_trunc, u, u_ in; u out
             "gram": N * S * 16 + N * 8 * (n_c + n_u),          # V, D, R_trunc, u in (unfused levels only)
         }
         dom = max(("rowpass", "gram"), key=lambda k: fam[k][0])
-        kernel_names = {0: {"rowpass": "k_rowpass_fused", "gram": "k_gram_reduce"},
-                        3: {"rowpass": "k_u_phase_mfma", "gram": "k_gram_u"},
-                        1: {"rowpass": "k_u_phase_gram", "gram": "k_gram"},
-                        2: {"rowpass": "k_u_step_direct", "gram": "k_gram"}}[args.kernels]
+        names = dict(tok.split("=", 1) for tok in kernels.split() if "=" in tok and tok.split("=")[0] in ("rowpass", "gram", "alpha"))
+        dom_kernel = names.get(dom, dom)
+        if dom == "gram" and dom_kernel == "fused":
+            dom_kernel = "k_gram_reduce"
         dom_ms = fam_ms[dom][0]
         achieved = per_launch_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get(args.workload, {}).get(kernel_names[dom], {}).get("hbm_bytes_per_launch")
+                tj = json.loads(tfile.read_text())
+                entry = tj.get(args.workload, {}).get(dom_kernel.split("<")[0], {})
+                traffic = entry.get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    # NOT measured in this run: a rocprofv3 PMC capture (profiles/README.md) of the commit named here
+                    traffic_source = f"profiles/traffic.json@{tj.get('_commit', 'unknown')} (rocprofv3 --pmc, separate run)"
             except Exception:
                 traffic = None
         ms_per_step = elapsed / args.steps * 1e3
+        loop_rate = iters_total / loop_s if loop_s > 0 else 0.0
         out = {
             "metric": "NMF update iters/sec (1e6 CpG x 256 samples x 16 types)" if args.workload.startswith("headline")
                       else f"NMF update iters/sec ({args.workload})",
-            "value": world * args.steps / elapsed,
+            "value": R * args.steps / elapsed,
             "unit": "outer iters/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic (SURVEY 8d recipe; small factors legacy numpy, N x S draws torch Philox on device)",
             "config": {"workload": args.workload, "N_cpg": N, "S_samples": S, "n_known": n_c, "n_unknown": n_u,
-                       "inner_iters": 20, "unit_of_work": "one outer iteration = 20 u + 20 alpha inner updates + cost",
-                       "parallelism": f"restart-sharded x{world}" if world > 1 else "single solve"},
+                       "inner_iters": T2, "restarts": R, "restart_seed": "1 + k", "restart_placement": "k mod n_gpus",
+                       "unit_of_work": "one step = one outer iteration (20 u + 20 alpha inner updates + cost) of each "
+                                       "of the R restarts; timed: host init + upload + set-up + K iterations + "
+                                       "cost_f_w per restart, one all-reduce(min), winner broadcast",
+                       "parallelism": f"restart-sharded x{world}", "kernels": kernels,
+                       "best_restart": int(best_k), "best_restart_cost": float(costs[best_k]), "head": git_head()},
+            # rank 0's K-iteration loops alone (what a single solve sustains; round 1 reported this as value)
+            "loop_only": {"value": loop_rate, "unit": "outer iters/s per GPU", "ms_per_outer_iteration": 1e3 / loop_rate if loop_rate else None,
+                          "restarts_on_rank0": len(mine), "job_seconds": elapsed, "loop_seconds_rank0": loop_s},
             "roofline": {
-                "bound": "hbm", "kernel": kernel_names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": per_launch_bytes[dom],
                 "avg_launch_ms": dom_ms,
+                # the same launch against the FP64 roof (SURVEY 8d flop count of the one-pass form; FP64 MFMA and
+                # FP64 VALU share one pipe on gfx950): whichever fraction is larger binds
+                "fp64": {"flop_per_launch": flops, "achieved": flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / (dom_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if dom_ms > 0 else 0.0},
                 "whole_iteration": {"algorithmic_bytes": b_alg,
-                                    "achieved": b_alg / (ms_per_step * 1e-3) / 1e9,
-                                    "frac": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                    "achieved": b_alg * loop_rate / 1e9,
+                                    "frac": b_alg * loop_rate / 1e9 / HBM_PEAK_GBS},
                 "family_avg_ms": {k: round(v[0], 4) for k, v in fam_ms.items()},
                 "family_launches": {k: v[1] for k, v in fam_ms.items()},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            n_s = min(args.cpu_rows, N)
-            out["cpu_baseline"] = cpu_baseline(V[:n_s].cpu().numpy(), D[:n_s].cpu().numpy().astype(np.int64),
-                                               Rt[:n_s].cpu().numpy(), n_u, N)
+            out["cpu_baseline"] = cpu_baseline(V, D, Rt, n_u, N)
         else:
             out["cpu_baseline"] = None
-        if world > 1:
-            out["config"]["best_restart_rank"] = int(best_rank)
-            out["config"]["best_restart_cost"] = float(best_cost)
         print(json.dumps(out), flush=True)
 
-    solver.close()
     problem.close()
     ctx.close()
     if world > 1:

@@ -15,6 +15,7 @@ DMF_PTR_DEVICE = 1
 DMF_COUNTS_F64 = 2
 DMF_MODE_PARTIAL = 0
 DMF_MODE_UNSUPERVISED = 1
+MAX_K = 64  # dmf::kMaxK: largest n_c + n_u the kernels are built for (DMF_ERR_UNSUPPORTED beyond)
 KERNEL_ROWPASS, KERNEL_GRAM, KERNEL_ALPHA, KERNEL_COST = 0, 1, 2, 3
 KERNEL_FAMILIES = ("rowpass", "gram", "alpha", "cost")
 
@@ -47,7 +48,9 @@ SIGNATURES = {
     "dmf_solver_set_purity": (C.c_int, [_p, _p, C.c_int]),
     "dmf_solver_step": (C.c_int, [_p, _i64, _i64, C.c_double, C.POINTER(_i64), C.POINTER(C.c_int)]),
     "dmf_solver_get": (C.c_int, [_p, C.c_int, _p, _p, _dbl_p, C.POINTER(_i64)]),
+    "dmf_solver_cost": (C.c_int, [_p, _dbl_p]),
     "dmf_solver_destroy": (C.c_int, [_p]),
+    "dmf_solver_describe": (C.c_int, [_p, _i64, C.c_char_p, _i64]),
     "dmf_solve": (C.c_int, [_p, _p, _p, _p, _i64, C.c_int, _i64, _i64, C.c_double, C.c_int, _p, _p,
                             _dbl_p, C.POINTER(_i64)]),
 }

@@ -301,7 +301,7 @@ int enqueue_u_phase(dmf_solver* s, int n_iter2) {
                                         (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
         return DMF_OK;
     }
-    if (s->u_path == 0 && n_iter2 > kSplitInnerSteps && n_iter2 <= 6144) {
+    if (s->u_path == 0 && n_iter2 > kSplitInnerSteps) {
         // many inner steps: one wave per workgroup running them is the bottleneck (see enqueue_outer_iteration)
         if (s->cm == nullptr)
             HIP_TRY(pool_alloc(ctx, (void**)&s->cm, (size_t)dmf::u_phase_split_cm_doubles(p->N, (int)s->n_u) * sizeof(double)));
@@ -824,6 +824,21 @@ int dmf_solver_get(dmf_solver* s, int flags, double* out_u, double* out_alpha, d
     return DMF_OK;
 }
 
+int dmf_solver_cost(dmf_solver* s, double* out_cost) {
+    if (s == nullptr || out_cost == nullptr) return DMF_ERR_BAD_ARG;
+    dmf_context* ctx = s->ctx;
+    DMF_TRY(check_ctx(ctx));
+    const dmf_problem* p = s->p;
+    {
+        FamilyScope scope(ctx, DMF_KERNEL_COST);
+        HIP_TRY(dmf::launch_cost(p->V, p->D, p->Rt, s->u, s->alpha, p->N, (int)p->S, (int)p->n_c, (int)s->n_u,
+                                 ctx->scratch + 1024, ctx->scratch + 3072, ctx->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(out_cost, ctx->scratch + 3072, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DMF_OK;
+}
+
 int dmf_solver_destroy(dmf_solver* s) {
     if (s == nullptr) return DMF_OK;
     dmf_context* ctx = s->ctx;
@@ -847,6 +862,34 @@ int dmf_solver_destroy(dmf_solver* s) {
     pool_free(ctx, s->job_l);
     pool_free(ctx, s->job_dst);
     delete s;
+    return DMF_OK;
+}
+
+int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t cap) {
+    if (s == nullptr || buf == nullptr || cap < 1) return DMF_ERR_BAD_ARG;
+    const dmf_problem* p = s->p;
+    const int S = (int)p->S, n_c = (int)p->n_c, n_u = (int)s->n_u, K = n_c + n_u;
+    char row[160], gram[64];
+    if (s->use_fused && n_iter2 <= kSplitInnerSteps) {
+        const int64_t n_full = p->N - (p->N & 15);
+        snprintf(row, sizeof(row), "k_rowpass_fused<%d,%d> nw=%d grid=%d tail=%d", (n_c + 3) / 4, n_u, (S + 63) / 64,
+                 dmf::rowpass_fused_grid(n_full, S), (int)(p->N & 15));
+        snprintf(gram, sizeof(gram), "fused");
+    } else {
+        if (s->use_u_big && dmf::u_phase_big_supported(S, n_c, n_u, (int)n_iter2)) snprintf(row, sizeof(row), "k_u_phase_big");
+        else if (s->u_path == 0 && n_iter2 > kSplitInnerSteps) snprintf(row, sizeof(row), "k_u_phase_mfma(split)+k_u_inner_rows");
+        else if (s->u_path == 0) snprintf(row, sizeof(row), "k_u_phase_mfma");
+        else if (s->u_path == 1) snprintf(row, sizeof(row), "k_u_phase_gram");
+        else snprintf(row, sizeof(row), "k_u_step_direct");
+        snprintf(gram, sizeof(gram), "%s", s->use_gram_spec ? "k_gram_u" : s->use_gram_mfma ? "k_gram_mfma" : "k_gram");
+    }
+    const bool tps = s->ctx->generic_level == 1 || s->ctx->generic_level == 2;
+    const char* alpha = s->purity != nullptr ? (K <= 16 && n_c >= 1 ? "k_alpha_frank_wolfe_row16" : "k_alpha_frank_wolfe")
+                        : (!tps && K <= 16)  ? "k_alpha_phase_row16"
+                        : (!tps && K <= 32)  ? "k_alpha_phase_lanes"
+                        : (tps && K <= 16)   ? "k_alpha_phase"
+                                             : "k_alpha_phase_dyn";
+    snprintf(buf, (size_t)cap, "rowpass=%s gram=%s alpha=%s", row, gram, alpha);
     return DMF_OK;
 }
 

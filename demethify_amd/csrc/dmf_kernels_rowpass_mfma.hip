@@ -362,6 +362,8 @@ __global__ void k_beta_table(const SolverState* __restrict__ state, int n_iter2,
     }
 }
 
+constexpr int kBetaChunk = 6144;  // momentum coefficients held in LDS at a time (48 KB)
+
 template <int NU>
 __global__ __launch_bounds__(256) void k_u_inner_rows(const double* __restrict__ cm, const double* __restrict__ beta_g,
                                                       double* __restrict__ u, double* __restrict__ u_prev,
@@ -371,8 +373,6 @@ __global__ __launch_bounds__(256) void k_u_inner_rows(const double* __restrict__
     constexpr int RPW = 64 / NU;  // rows per wave
     extern __shared__ double beta_tab[];
     if (state->done) return;
-    for (int t = threadIdx.x; t < n_iter2; t += 256) beta_tab[t] = beta_g[t];
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rl = lane / NU, j = lane - rl * NU, lane0 = lane - j;
     const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * RPW + rl;
@@ -386,13 +386,20 @@ __global__ __launch_bounds__(256) void k_u_inner_rows(const double* __restrict__
     for (int l = 0; l < NU; ++l) Mrow[l] = mine[NU + (l <= j ? tri(l, j) : tri(j, l))];
     const int64_t gi = rowc * NU + j;
     double uu = u[gi], up = u_prev[gi];
-    for (int t2 = 0; t2 < n_iter2; ++t2) {  // same arithmetic as the inner loop of k_u_phase_mfma
-        const double beta = beta_tab[t2];
-        const double ut = uu + beta * (uu - up);
-        const double base = mode == 1 ? uu : ut;  // deconvolution.py:163 vs :88
-        up = uu;
-        const double g = grad_row<NU>(cj, base, Mrow, lane0);
-        uu = fmin(fmax(fma(g, inv_lw, ut), 0.0), 1.0);
+    // the momentum coefficients pass through LDS kBetaChunk at a time: any n_iter2 runs (the reference has no limit)
+    for (int t0 = 0; t0 < n_iter2; t0 += kBetaChunk) {
+        const int nt = n_iter2 - t0 < kBetaChunk ? n_iter2 - t0 : kBetaChunk;
+        if (t0 > 0) __syncthreads();  // the previous chunk has been consumed by every wave
+        for (int t = threadIdx.x; t < nt; t += 256) beta_tab[t] = beta_g[t0 + t];
+        __syncthreads();
+        for (int t2 = 0; t2 < nt; ++t2) {  // same arithmetic as the inner loop of k_u_phase_mfma
+            const double beta = beta_tab[t2];
+            const double ut = uu + beta * (uu - up);
+            const double base = mode == 1 ? uu : ut;  // deconvolution.py:163 vs :88
+            up = uu;
+            const double g = grad_row<NU>(cj, base, Mrow, lane0);
+            uu = fmin(fmax(fma(g, inv_lw, ut), 0.0), 1.0);
+        }
     }
     if (ok) {
         u[gi] = uu;
@@ -406,11 +413,11 @@ int64_t u_phase_split_cm_doubles(int64_t N, int n_u) { return N * (n_u + (int64_
 hipError_t launch_u_phase_split(const double* V, const double* D, const double* Rt, const double* alpha, double* u,
                                 double* u_prev, const SolverState* state, int64_t N, int S, int n_c, int n_u,
                                 int n_iter2, int mode, double* cm, double* beta, hipStream_t st) {
-    if (cm == nullptr || beta == nullptr || (size_t)n_iter2 * sizeof(double) > 48 * 1024) return hipErrorInvalidValue;
+    if (cm == nullptr || beta == nullptr) return hipErrorInvalidValue;
     hipError_t e = launch_u_phase_mfma_impl(V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_u, n_iter2, mode, cm, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_beta_table, dim3(1), dim3(1), 0, st, state, n_iter2, beta);
-    const size_t lds = (size_t)n_iter2 * sizeof(double);
+    const size_t lds = (size_t)(n_iter2 < kBetaChunk ? n_iter2 : kBetaChunk) * sizeof(double);
 #define DMF_CASE(NU_)                                                                                          \
     case NU_: {                                                                                                \
         const int64_t rows_per_block = 4 * (64 / NU_);                                                         \

@@ -10,6 +10,8 @@ Deliberate differences from upstream, all flagged at run time:
   * ``--restart r``: upstream re-runs the SAME seed r times; here restart k > 0 uses seed + k
     (restart 0 is bit-compatible), SURVEY.md section 8b.
   * ``--plot`` is ignored with a note and ``--init SVD|ICA`` exits with a message (outside this build's scope).
+  * ``--ic NAME [n [lo hi]]``: upstream sweeps the hard-coded range 1..25 (ic.py:171); two more values after the
+    restart count restrict the sweep to lo..hi unknown types (``--ic BIC 5 2 12``).  Without them: 1..25, as upstream.
 """
 from __future__ import annotations
 
@@ -56,7 +58,7 @@ def build_parser():
     return parser
 
 
-def read_inputs(args):
+def read_inputs(args, parsed=None):
     """demethify.py:102-143: bedmethyl (tab separated, percent) or csv (fractions) input.  The per-sample files
     are parsed in parallel (and 1 / world of them per rank when distributed): demethify_amd/tables.py."""
     ref, header = None, []
@@ -69,7 +71,7 @@ def read_inputs(args):
             table = table.fillna(0)
         header = list(table.columns)
         ref = table.values
-    meth_f, counts = tables.read_samples(args.methfreq, bool(args.bedmethyl), bool(args.fillna))
+    meth_f, counts = tables.read_samples(args.methfreq, bool(args.bedmethyl), bool(args.fillna), parsed=parsed)
     return ref, header, meth_f, counts
 
 
@@ -115,12 +117,22 @@ def main(argv=None):
             sys.exit(1)
         purity = 1 - (purity / 100.0)
     nb_r = 5
+    ic_range = None
     if args.ic:
         if args.nbunknown:
             sys.stderr.write("Error: --ic cannot be used with --nbunknown.\n")
             sys.exit(1)
         if len(args.ic) > 1:
             nb_r = int(args.ic[1])
+        if len(args.ic) == 4:  # extension: candidate range lo..hi (upstream ignores anything after the count)
+            lo, hi = int(args.ic[2]), int(args.ic[3])
+            if lo < 1 or hi < lo:
+                sys.stderr.write("Error: --ic NAME n lo hi needs 1 <= lo <= hi.\n")
+                sys.exit(1)
+            ic_range = range(lo, hi + 1)
+        elif len(args.ic) > 2:
+            sys.stderr.write("Error: --ic takes NAME [n_restarts [lo hi]].\n")
+            sys.exit(1)
         args.ic = args.ic[0]
     if args.init in ("SVD", "ICA"):
         sys.stderr.write(f"Error: --init {args.init} (one-shot LAPACK initialiser, demethify/init_func.py) is not part "
@@ -129,6 +141,9 @@ def main(argv=None):
     if args.plot:
         sys.stderr.write("Note: --plot is ignored, plotting (seaborn/colorcet) is outside this build's scope.\n")
 
+    # this rank's share of the sample files is parsed BEFORE the process group / the GPU come up: the parser's
+    # worker pool is forked, and a fork must not start from a process that holds a HIP runtime and RCCL threads
+    parsed = tables.parse_share(args.methfreq, bool(args.bedmethyl), bool(args.fillna))
     rank = _init_distributed()
     if not args.noprint and rank == 0:
         print(logo)
@@ -139,15 +154,16 @@ def main(argv=None):
     if args.nbunknown is None:
         args.nbunknown = [0]
 
-    ref, header, meth_f, counts = read_inputs(args)
+    ref, header, meth_f, counts = read_inputs(args, parsed)
+    del parsed
     args.methfreq = [name.split("/")[-1] for name in args.methfreq]
 
     # imported late so that ``--help`` and argument errors work on a box without the GPU library
     from . import _lib as L
     from . import shard
     from .bootstrap import bt_ci
-    from .deconvolution import _init_unsupervised, init_BSSMF_md, init_BSSMF_md_p, solve_problem
-    from .device import Problem, get_context
+    from .deconvolution import _init_unsupervised, init_BSSMF_md, init_BSSMF_md_p
+    from .device import Problem, Solver, get_context
     from .ic import evaluate_best_ic
     from .init_func import wls_intercept
 
@@ -162,7 +178,7 @@ def main(argv=None):
     if args.ic:
         ref_estimate, proportions, ic_n_u, _scores = evaluate_best_ic(
             meth_f, ref, counts, args.init, args.ic, args.seed, iter1=args.iterations[0], iter2=args.iterations[1],
-            tol=args.termination, n_restarts=nb_r)
+            tol=args.termination, n_restarts=nb_r, n_u_values=ic_range)
         unknown_header = ["unknown_cell_" + str(i + 1) for i in range(ic_n_u)]
         header = header + unknown_header
     elif (not args.ref) or (n_u > 0 and meth_f.shape[1] >= 1):
@@ -173,7 +189,7 @@ def main(argv=None):
         if args.restart > 1 and rank == 0:
             print(f"restart k > 0 uses seed + k (upstream repeats the same seed); {args.restart} restarts")
         with Problem(get_context(), meth_f, counts, None if unsupervised else ref) as problem:
-            def solve_one(k):
+            def solve_one(k, best_cost):
                 seed_k = shard.restart_seed(args.seed, k)
                 if unsupervised:
                     u0, a0 = _init_unsupervised(args.init, meth_f, n_u, seed_k)
@@ -185,9 +201,15 @@ def main(argv=None):
                 else:
                     u0, _, a0 = init_BSSMF_md(args.init, meth_f, counts, ref, n_u, rb_alg=wls_intercept, seed=seed_k)
                     mode = L.DMF_MODE_PARTIAL
-                u, alpha = solve_problem(problem, u0, a0, mode, args.iterations[0], args.iterations[1], args.termination,
-                                         purity=None if unsupervised else purity)
-                return u, alpha, problem.cost(u, alpha)  # cost_f_w recomputed per restart, demethify.py:169,199
+                with Solver(problem, u0, a0, mode) as s:
+                    if purity is not None and not unsupervised:
+                        s.set_purity(purity)
+                    s.step(args.iterations[0], args.iterations[1], args.termination)
+                    cost = s.direct_cost()  # cost_f_w recomputed per restart, demethify.py:169,199
+                    if not cost < best_cost and args.restart > 1:
+                        return None, None, cost  # cannot win (strict '<', demethify.py:170,200): stays on the device
+                    u, alpha, _, _ = s.get()
+                return u, alpha, cost
 
             ref_estimate, proportions, _best, _costs = shard.sharded_restarts(
                 args.restart, solve_one, ((meth_f.shape[0], n_u), (K, meth_f.shape[1])))

@@ -302,6 +302,19 @@ class Solver:
                 "dmf_solver_get")
         return u, alpha, cost.value, it.value
 
+    def direct_cost(self) -> float:
+        """cost_f_w of the current iterate by the streaming formula (deconvolution.py:15-17), computed where the
+        iterate lives: what demethify.py:169,199 and ic.py:206 recompute after a solve."""
+        out = C.c_double()
+        L.check(self._lib.dmf_solver_cost(self._h, C.byref(out)), "dmf_solver_cost")
+        return out.value
+
+    def describe(self, n_iter2: int = 20) -> str:
+        """Which kernels a step with n_iter2 inner iterations launches (dmf_solver_describe)."""
+        buf = C.create_string_buffer(512)
+        L.check(self._lib.dmf_solver_describe(self._h, int(n_iter2), buf, len(buf)), "dmf_solver_describe")
+        return buf.value.decode()
+
     def get_cost(self):
         """(cost, iterations) of the current iterate without copying u / alpha back."""
         cost, it = C.c_double(), C.c_int64()

@@ -137,21 +137,38 @@ def evaluate_best_ic(meth_f, ref, counts, init_option, ic, seed, iter1, iter2, t
 
     # AIC / BIC: one solve per candidate; candidates dealt to ranks longest-first (cost grows with n_u)
     rank, world, _ = shard.dist_state()
+    too_many = [n for n in n_u_values if n_ct + n > L.MAX_K or n < 1]
+    if too_many:  # checked on every rank before any solve, so that all ranks fail together
+        raise ValueError(f"candidate n_u values {too_many} need more than {L.MAX_K} cell types in total "
+                         f"({n_ct} known): outside what the kernels are built for")
     order = sorted(range(len(n_u_values)), key=lambda i: -n_u_values[i])
     mine = [order[i] for i in range(rank, len(order), world)]
     formula = compute_bic if ic == "BIC" else compute_aic
-    local, keep = [], {}
+    local, keep = [], None  # keep = this rank's best candidate only (the reference keeps the running best, ic.py:212)
     with Problem(get_context(), meth_f, counts, ref) as problem:
         for i in mine:
             n_u = n_u_values[i]
             u, alpha = _solve(problem, meth_f, counts, ref, n_u, init_option, seed, iter1, iter2, tol)
             cost = problem.cost(u, alpha)  # cost_f_w(meth_f, R, alpha, counts), ic.py:206
-            local.append((i, float(formula(cost, n_u, n_cpg, n_ct, n_samples))))
-            keep[i] = (u, alpha)
+            score = float(formula(cost, n_u, n_cpg, n_ct, n_samples))
+            local.append((i, score))
+            # strict '<' on the score, lowest candidate index among equal scores: what ic.py:212 does serially
+            # (a NaN score never wins, exactly as `ic_result < best_ic` upstream)
+            if score < (keep[0] if keep else float("inf")) or (keep and score == keep[0] and i < keep[1]):
+                keep = (score, i, u, alpha)
     scores = [s for _, s in shard.gather_objects(local)]
-    best_i = int(np.argmin(scores))  # first strict minimum, ic.py:212
+    best_i, best_score = None, float("inf")
+    for i, score in enumerate(scores):  # running strict minimum in candidate order, ic.py:212-216
+        if score < best_score:
+            best_i, best_score = i, score
+    if best_i is None:  # every score NaN / inf: upstream returns its initial Nones
+        return None, None, None, scores
     n_best = n_u_values[best_i]
     owner = order.index(best_i) % world
-    payload = keep[best_i] if rank == owner else (np.empty((n_cpg, n_best)), np.empty((n_ct + n_best, n_samples)))
+    if rank == owner:
+        assert keep is not None and keep[1] == best_i
+        payload = (keep[2], keep[3])
+    else:
+        payload = (np.empty((n_cpg, n_best)), np.empty((n_ct + n_best, n_samples)))
     u, alpha = shard.broadcast_arrays(payload, owner)
     return u, alpha, n_best, scores

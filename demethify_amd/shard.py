@@ -162,13 +162,14 @@ def restart_seed(seed, k):
 def sharded_restarts(n_restarts, solve_one, shapes):
     """Run restarts k = 0..n_restarts-1 across the ranks and return the min-cost one everywhere.
 
-    solve_one(k) -> (u, alpha, cost) runs restart k on this rank's GPU; ``shapes`` = (u.shape,
-    alpha.shape) lets non-owner ranks allocate the broadcast buffers.  Returns
-    (u, alpha, best_k, cost_vector)."""
+    solve_one(k, best_cost) -> (u, alpha, cost) runs restart k on this rank's GPU; it may return (None, None,
+    cost) when cost >= best_cost (this rank's running minimum: the iterate of a restart that cannot win need not
+    leave the device).  ``shapes`` = (u.shape, alpha.shape) lets non-owner ranks allocate the broadcast buffers.
+    Returns (u, alpha, best_k, cost_vector)."""
     rank, world, _ = dist_state()
     local_costs, keep = {}, {}
     for k in my_items(n_restarts, rank, world):
-        u, alpha, cost = solve_one(k)
+        u, alpha, cost = solve_one(k, keep["cost"] if keep else float("inf"))
         local_costs[k] = cost
         # keep only the local best: strict '<' so that the lowest k wins ties locally as well
         if not keep or cost < keep["cost"]:
@@ -177,7 +178,7 @@ def sharded_restarts(n_restarts, solve_one, shapes):
     best_k = argmin_first(costs)
     owner = best_k % world
     if rank == owner:
-        assert keep["k"] == best_k
+        assert keep["k"] == best_k and keep["u"] is not None
         payload = (keep["u"], keep["alpha"])
     else:
         payload = (np.empty(shapes[0]), np.empty(shapes[1]))

@@ -88,12 +88,32 @@ def _stack(columns, n_rows, dtype):
     return out
 
 
-def read_samples(paths, bedmethyl: bool, fillna: bool):
-    """All sample files -> (meth_f, counts), both (N, S) in C order, equal to upstream's column_stack of the
-    per-file columns (same dtypes: counts stay int64 unless a file forces float)."""
-    rank, world, dev = shard.dist_state()
+def env_rank_world():
+    """(rank, world) of a torch.distributed.run launch, from the environment: known before the process group (and
+    with it the GPU runtime) exists."""
+    return int(os.environ.get("RANK", "0")), max(1, int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def parse_share(paths, bedmethyl: bool, fillna: bool):
+    """Parse this rank's 1 / world share of the sample files.  Needs RANK / WORLD_SIZE only, so the CLI calls it
+    BEFORE the process group and the device are initialised: the worker pool is then always forked from a process
+    that has not touched the GPU (a fork of a process that holds a HIP runtime and RCCL threads inherits locked
+    mutexes and the KFD file descriptor)."""
+    rank, world = env_rank_world()
     mine = shard.my_items(len(paths), rank, world)
-    parsed = _read_many([paths[i] for i in mine], bedmethyl, fillna)
+    return _read_many([paths[i] for i in mine], bedmethyl, fillna)
+
+
+def read_samples(paths, bedmethyl: bool, fillna: bool, parsed=None):
+    """All sample files -> (meth_f, counts), both (N, S) in C order, equal to upstream's column_stack of the
+    per-file columns (same dtypes: counts stay int64 unless a file forces float).  ``parsed`` = the result of an
+    earlier parse_share() of the same arguments on this rank (the CLI parses before it initialises the GPU)."""
+    rank, world, dev = shard.dist_state()
+    if parsed is None:
+        mine = shard.my_items(len(paths), rank, world)
+        parsed = _read_many([paths[i] for i in mine], bedmethyl, fillna)
+    elif world > 1:
+        assert (rank, world) == env_rank_world(), "parse_share() ran under a different rank layout"
     if world == 1:
         freqs = [f for f, _ in parsed]
         counts = [c for _, c in parsed]

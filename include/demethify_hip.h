@@ -141,7 +141,16 @@ int dmf_solver_step(dmf_solver* s, int64_t n_outer, int64_t n_iter2, double tol,
                     int64_t* iters_done_total, int* converged);
 int dmf_solver_get(dmf_solver* s, int flags, double* out_u, double* out_alpha,
                    double* out_cost, int64_t* out_iters);
+/* cost_f_w(meth_f, [Rt | u], alpha, counts) of the solver's CURRENT iterate by the streaming formula
+ * (deconvolution.py:15-17), without moving u / alpha to the host: what the restart and model-selection loops
+ * recompute after every solve (demethify.py:169,199; ic.py:206).  out_cost: host double. */
+int dmf_solver_cost(dmf_solver* s, double* out_cost);
 int dmf_solver_destroy(dmf_solver* s);
+/* Which kernels a step with n_iter2 inner iterations would launch for this solver, as text, e.g.
+ * "rowpass=k_rowpass_fused<3,4> nw=4 grid=256 tail=5 gram=fused alpha=k_alpha_phase_row16".  For tests (every
+ * parity case asserts the path it means to cover) and for bench.py's kernel label.  buf gets at most cap bytes
+ * including the terminator. */
+int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t cap);
 /* One-shot convenience: create + step(n_iter1) + get + destroy. */
 int dmf_solve(dmf_context* ctx, const dmf_problem* p, const double* u0, const double* alpha0,
               int64_t n_u, int mode, int64_t n_iter1, int64_t n_iter2, double tol, int flags,

@@ -70,6 +70,10 @@ def test_argument_errors(tmp_path):
                 "--init", "SVD", expect=1)
     assert "not part of this build" in p.stderr
     run_cli("--methfreq", *SAMPLES, expect=2)  # --outdir is required
+    # --ic NAME [n [lo hi]]: a candidate range needs both ends and 1 <= lo <= hi
+    for bad in (["BIC", "5", "3"], ["BIC", "5", "4", "2"], ["BIC", "5", "0", "3"], ["BIC", "5", "2", "3", "4"]):
+        p = run_cli("--methfreq", *SAMPLES, "--bedmethyl", "--outdir", str(tmp_path), "--ic", *bad, expect=1)
+        assert "--ic" in p.stderr
 
 
 def test_flag_surface_matches_reference():
@@ -118,6 +122,22 @@ def test_model_selection_command_reproduces_committed_outputs(tmp_path):
     run_cli("--ref", REF, "--methfreq", *SAMPLES, "--bedmethyl", "--ic", "AIC", "--outdir", str(tmp_path), "--noprint")
     assert (tmp_path / "log.log").read_text().strip().endswith("Number of unknowns that minimises AIC : 10")
     same_csv(tmp_path / "celltypes_proportions.csv", UPSTREAM / "model_selection" / "celltypes_proportions.csv", 1e-7)
+
+
+@pytest.mark.gpu
+def test_unsupervised_bic_range_command(tmp_path, toy):
+    """BASELINE.json configs[4] through the CLI: no --ref, `--ic BIC 5 2 4` sweeps n_u = 2..4 only (upstream
+    hard-codes 1..25, ic.py:171); scores and winner against the oracle's sweep."""
+    V, D, _, _ = toy
+    run_cli("--methfreq", *SAMPLES, "--bedmethyl", "--ic", "BIC", "5", "2", "4", "--iterations", "40", "20",
+            "--outdir", str(tmp_path), "--noprint")
+    wu, wa, wn, _ = odrv.ic_sweep(V, None, D, "uniform_", "BIC", 1, 40, 20, 1e-2, n_u_values=range(2, 5))
+    assert (tmp_path / "log.log").read_text().strip().endswith(f"Number of unknowns that minimises BIC : {wn}")
+    got = pd.read_csv(tmp_path / "celltypes_proportions.csv", index_col=0)
+    assert list(got.index) == [f"unknown_cell_{i + 1}" for i in range(wn)]
+    assert np.abs(got.values - wa).max() < 1e-8
+    prof = pd.read_csv(tmp_path / "methylation_profile_estimate.csv")
+    assert np.abs(prof.values - wu).max() < 1e-8
 
 
 @pytest.mark.gpu

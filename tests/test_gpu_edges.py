@@ -51,6 +51,15 @@ def test_inner_iteration_counts(T2):
     assert np.abs(ga - wa).max() < TIGHT and np.abs(gu - wu).max() < TIGHT
 
 
+@pytest.mark.parametrize("T2", [7000, 20000])
+def test_very_many_inner_iterations(T2):
+    """The reference runs any n_iter2; the momentum table of the inner steps passes through LDS in chunks of 6144
+    (k_u_inner_rows), so there is no size at which the device path starts to refuse."""
+    V, D, Rt = osol.synthetic_problem(48, 6, 3, 2, seed=8, depth=12)
+    (gu, ga), (wu, wa) = _run_both(V, D, Rt, 2, 1, T2, 0.0)
+    assert np.abs(ga - wa).max() < TIGHT and np.abs(gu - wu).max() < TIGHT
+
+
 def test_zero_coverage_entries_and_fractional_weights():
     """coverage 0 (what --fillna produces) and non-integer weights (not exact in f32: the fused tile format
     must be refused and the f64 kernels used)"""

@@ -29,6 +29,30 @@ def test_config2_full_size_against_oracle(ctx):
     assert cost == pytest.approx(want, rel=1e-10) and direct == pytest.approx(want, rel=1e-12)
 
 
+def test_config2_natural_stop_matches_oracle(ctx):
+    """Stop-iteration parity at a BASELINE size ("plus natural-stop parity run" for config 2).
+    tol = 2e5 makes the oracle's |cf - cf_0| < tol (deconvolution.py:220) fire at outer iteration 10 (its cost
+    differences there: ... 2.6e5, 1.4e5, 6.4e4); the device must freeze the iterate at the same iteration."""
+    from demethify_amd import _lib as L
+    from demethify_amd.deconvolution import solve_problem
+    from demethify_amd.device import Problem
+
+    V, D, Rt = osol.synthetic_problem(100_000, 64, 6, 2, seed=0, depth=50)
+    u0, R, a0 = osol.init_partial("uniform_", V, D, Rt, 2, seed=1)
+    trace = []
+    wu, wa = osol.solve_partial(u0.copy(), R, a0.copy(), V, D, Rt, 2, 50, 20, 2e5, trace=trace,
+                                project=osol.simplex_project_columns_fast)
+    assert len(trace) == 10
+    with Problem(ctx, V, D, Rt) as p:
+        gu, ga, cost, iters = solve_problem(p, u0, a0, L.DMF_MODE_PARTIAL, 50, 20, 2e5, return_info=True)
+        direct = p.cost(gu, ga)
+    assert iters == len(trace)
+    assert rel_err(ga, wa) < 1e-8 and np.abs(ga - wa).max() < 1e-8 and np.abs(gu - wu).max() < 1e-8
+    # the Gram-form cost the stop test uses against the streaming cost of the same iterate, in ABSOLUTE terms:
+    # the CLI's default threshold is 1e-2 (demethify.py:35)
+    assert abs(cost - direct) < 1e-4 and abs(direct - trace[-1]) < 1e-4 * max(1.0, abs(trace[-1]) * 1e-9)
+
+
 def test_headline_size_properties(ctx):
     """1e6 x 256, 12 + 4 (the bench workload): invariants of the iteration instead of an oracle run."""
     torch = pytest.importorskip("torch")
@@ -49,9 +73,12 @@ def test_headline_size_properties(ctx):
             for _ in range(3):
                 s.step(1, 20, 0.0)
                 costs.append(s.get_cost()[0])
+                # the cost the stop test uses (Gram form: v'Dv - 2 a.b + a'Ga, v'Dv ~ 4e9 here) against the
+                # streaming cost of the same iterate, in ABSOLUTE terms: the stop threshold of the CLI is 1e-2
+                # (demethify.py:35), so the cancellation error must stay orders of magnitude below that
+                assert abs(s.direct_cost() - costs[-1]) < 1e-3
             u1, a1, c1, it1 = s.get()
-        # the cost the stop test uses (Gram form) equals the streaming cost of the same iterate
-        assert p.cost(u1, a1) == pytest.approx(c1, rel=1e-9)
+        assert p.cost(u1, a1) == pytest.approx(c1, rel=1e-9) and abs(p.cost(u1, a1) - c1) < 1e-3
         assert it1 == 3 and all(b < a for a, b in zip(costs, costs[1:]))  # monotone decrease from a random start
         # feasibility: proportions on the simplex, profiles in [0, 1]
         assert np.abs(a1.sum(axis=0) - 1).max() < 1e-12 and a1.min() >= 0

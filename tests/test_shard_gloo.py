@@ -28,7 +28,7 @@ def _toy():
     return V, D, Rt
 
 
-def _solve_restart(k):
+def _solve_restart(k, best_cost=float("inf")):
     from demethify_amd.shard import restart_seed
     from oracle import drivers as odrv
     from oracle import solver as osol
@@ -36,7 +36,10 @@ def _solve_restart(k):
     V, D, Rt = _toy()
     u, R, alpha = odrv.run_one(V, D, Rt, 1, "uniform_", restart_seed(1, k), 30, 5, 1e-3,
                                project=osol.simplex_project_columns_fast)
-    return u, alpha, float(osol.weighted_cost(V, R, alpha, D))
+    cost = float(osol.weighted_cost(V, R, alpha, D))
+    if not cost < best_cost:  # the product leaves such an iterate on the device
+        return None, None, cost
+    return u, alpha, cost
 
 
 def _worker(rank, world, port, out_dir):
