@@ -65,8 +65,15 @@ struct dmf_problem {
     bool own_V = false, own_D = false, own_Rt = false;
     double* Rtp = nullptr;       // R_trunc, rows zero-padded to a multiple of 4 doubles (== Rt if n_c % 4 == 0)
     bool own_Rtp = false;
-    double* consts = nullptr;    // device {dsq, ||Rt||^2, dmax, max |D - f32(D)|}
-    double h_consts[4] = {0, 0, 0, 0};
+    double* consts = nullptr;    // device {dsq, ||Rt||^2, dmax, max |D - f32(D)|, int-count max or inf, Rt outside [0,1]}
+    double h_consts[6] = {0, 0, 0, 0, 0, 0};
+    // integer copies of the counts for the second-generation kernels (dmf_kernels_rowpass2.hip, dmf_kernels_gram_i8.hip):
+    // built when every count is an integer in [0, 32639], S is even and <= 256 and R_trunc lies in [0, 1]
+    unsigned short* D16 = nullptr;  // [N16][SD], zero padded
+    signed char* Dt8 = nullptr;     // [ND][ceil(N / 32)][SD / 32][32][32] balanced 8-bit digits, MFMA B layout
+    int ND = 0;                     // count digits: 0 = no integer copies, 1 (d <= 127), 2 (d <= 32639)
+    int SD = 0;
+    int64_t N16 = 0, plane_stride = 0;
     bool d_f32_exact = false;    // every count survives a round trip through f32 (the fused tile stores D as f32)
     double* gb_known = nullptr;  // [(n_c+1)(n_c+2)/2][S]
 };
@@ -83,7 +90,9 @@ struct dmf_solver {
     double* cm = nullptr;        // split u phase (many inner steps): per-row c_i / M_i, allocated on first use
     double* beta_tab = nullptr;  //   and the momentum coefficients of the inner steps
     int64_t beta_cap = 0;  // shapes beyond the lane-per-sample kernel's registers: MFMA Gram
-    bool use_fused = false;
+    bool use_fused = false;      // first-generation fused row pass (counts as f64 in HBM, FP64 Gram in the kernel)
+    bool use_v2 = false;         // second generation: u16 counts in the row pass + integer-MFMA Gram
+    int* slab_i8 = nullptr;      // i32 partial sums of the integer Gram
     double* purity = nullptr;  // S per-sample known-block masses: set => Frank-Wolfe alpha phase
     double* u2_partials = nullptr;
     double *u = nullptr, *u_prev = nullptr, *u_next = nullptr;
@@ -201,7 +210,7 @@ int export_array(dmf_context* ctx, const void* dev_src, size_t bytes, int flags,
 int problem_finalize(dmf_problem* p) {
     dmf_context* ctx = p->ctx;
     const int64_t N = p->N, S = p->S, n_c = p->n_c;
-    HIP_TRY(pool_alloc(ctx, (void**)&p->consts, 4 * sizeof(double)));
+    HIP_TRY(pool_alloc(ctx, (void**)&p->consts, 6 * sizeof(double)));
     HIP_TRY(dmf::launch_max_f64(p->D, N * S, ctx->scratch, p->consts + 2, ctx->stream));
     if (n_c > 0) {
         HIP_TRY(dmf::launch_sumsq_f64(p->Rt, N * n_c, ctx->scratch + 1024, p->consts + 1, nullptr, ctx->stream));
@@ -209,13 +218,32 @@ int problem_finalize(dmf_problem* p) {
         HIP_TRY(hipMemsetAsync(p->consts + 1, 0, sizeof(double), ctx->stream));
     }
     HIP_TRY(dmf::launch_f32_residual_max(p->D, N * S, ctx->scratch + 2048, p->consts + 3, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(p->h_consts, p->consts, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(dmf::launch_int_count_max(p->D, N * S, ctx->scratch + 3072, p->consts + 4, ctx->stream));
+    if (n_c > 0) {
+        HIP_TRY(dmf::launch_unit_range_check(p->Rt, N * n_c, ctx->scratch, p->consts + 5, ctx->stream));
+    } else {
+        HIP_TRY(hipMemsetAsync(p->consts + 5, 0, sizeof(double), ctx->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(p->h_consts, p->consts, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     p->h_consts[0] = p->h_consts[2] * p->h_consts[2];  // d = max(D)**2, deconvolution.py:197
     p->d_f32_exact = p->h_consts[3] == 0.0;
     HIP_TRY(hipMemcpyAsync(p->consts, p->h_consts, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (!std::isfinite(p->h_consts[2]) || !std::isfinite(p->h_consts[1])) return DMF_ERR_NONFINITE;
+
+    // integer copies of the counts (u16 row-major for the row pass, 8-bit digit planes for the integer-MFMA Gram)
+    if (ctx->generic_level == 0 && p->h_consts[4] <= 32639.0 && p->h_consts[5] == 0.0 && (S & 1) == 0 && S <= 256 &&
+        n_c <= 16) {
+        p->ND = p->h_consts[4] <= 127.0 ? 1 : 2;
+        p->SD = (int)((S + 63) / 64 * 64);
+        p->N16 = (N + 15) / 16 * 16;
+        p->plane_stride = ((N + 31) / 32) * (p->SD / 32) * 1024;
+        HIP_TRY(pool_alloc(ctx, (void**)&p->D16, (size_t)p->N16 * p->SD * sizeof(unsigned short)));
+        HIP_TRY(pool_alloc(ctx, (void**)&p->Dt8, (size_t)p->plane_stride * p->ND));
+        HIP_TRY(dmf::launch_build_counts_int(p->D, N, (int)S, p->ND, p->D16, p->N16, p->SD, p->Dt8, p->plane_stride,
+                                             ctx->stream));
+    }
 
     // padded copy of R_trunc for the shape-specialised kernels (aligned, branch-free row loads)
     if (n_c > 0 && n_c <= 16) {
@@ -384,6 +412,29 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
     // the unfused u-phase kernel, which keeps three workgroups per CU busy, wins: measured at the headline size
     // with n_iter2 = 500 (the CLI default under --purity) 18.5 ms fused against 7.6 + 1.2 ms; the estimated
     // break-even is around 50 inner steps.
+    if (s->use_v2 && n_iter2 <= kSplitInnerSteps &&
+        dmf::rowpass_v2_supported((int)p->S, (int)p->n_c, (int)s->n_u, n_iter2)) {
+        // Second generation: one read of V (f64) and of the u16 counts for the u phase and b_u, then the exact
+        // integer-matrix-core GEMM for the u-dependent Gram entries on the 8-bit count planes.
+        const int S = (int)p->S, n_c = (int)p->n_c, n_u = (int)s->n_u;
+        const int nf = n_c * n_u + n_u * (n_u + 1) / 2;
+        int grid = 0, ny = 0;
+        {
+            FamilyScope scope(ctx, DMF_KERNEL_ROWPASS);
+            HIP_TRY(dmf::launch_rowpass_v2(p->V, p->D16, p->SD, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, S,
+                                           n_c, n_u, n_iter2, s->mode, s->slab, s->u2_partials, &grid, ctx->stream));
+        }
+        HIP_TRY(dmf::launch_finish_u_norm(s->u2_partials, grid, s->state, ctx->stream));
+        {
+            FamilyScope scope(ctx, DMF_KERNEL_GRAM);
+            HIP_TRY(dmf::launch_gram_i8(p->Dt8, p->plane_stride, p->SD, p->ND, p->Rt, s->u, p->N, n_c, n_u, s->job_k,
+                                        s->job_l, nf, s->slab_i8, &s->state->done, &ny, ctx->stream));
+            HIP_TRY(dmf::launch_gram_v2_reduce(s->slab_i8, ny, p->ND, nf, p->SD, s->slab, grid, n_u, S, s->job_dst, s->gb,
+                                               &s->state->done, ctx->stream));
+        }
+        DMF_TRY(enqueue_alpha_phase(s, n_iter2));
+        return DMF_OK;
+    }
     if (s->use_fused && n_iter2 <= kSplitInnerSteps) {
         // The fused kernel takes whole 16-row blocks; a ragged tail (< 16 rows) goes through the unfused
         // pair on offset pointers and contributes extra slab rows and one more ||u||^2 share.
@@ -560,7 +611,7 @@ int dmf_context_reset_kernel_time(dmf_context* ctx) {
 
 int dmf_context_set_generic(dmf_context* ctx, int enabled) {
     if (ctx == nullptr) return DMF_ERR_BAD_ARG;
-    if (enabled < 0 || enabled > 3) return DMF_ERR_BAD_ARG;
+    if (enabled < 0 || enabled > 4) return DMF_ERR_BAD_ARG;
     ctx->generic_level = enabled;
     return DMF_OK;
 }
@@ -660,6 +711,8 @@ int dmf_problem_destroy(dmf_problem* p) {
     if (p->own_Rtp) pool_free(ctx, p->Rtp);
     pool_free(ctx, p->consts);
     pool_free(ctx, p->gb_known);
+    pool_free(ctx, p->D16);
+    pool_free(ctx, p->Dt8);
     delete p;
     return DMF_OK;
 }
@@ -688,14 +741,17 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     s->p = p;
     s->n_u = n_u;
     s->mode = mode;
-    const bool fast = ctx->generic_level == 0 || ctx->generic_level == 3;
+    const bool fast = ctx->generic_level == 0 || ctx->generic_level == 3 || ctx->generic_level == 4;
     if (fast && dmf::u_phase_mfma_supported((int)S, (int)n_c, (int)n_u)) s->u_path = 0;
     else if (ctx->generic_level != 2 && dmf::u_phase_gram_supported((int)S, (int)n_c, (int)n_u)) s->u_path = 1;
     else s->u_path = 2;
     s->use_gram_spec = fast && dmf::gram_u_supported((int)n_c, (int)n_u);
     s->use_gram_mfma = fast && !s->use_gram_spec;
     s->use_u_big = fast && s->u_path != 0 && dmf::u_phase_big_supported((int)S, (int)n_c, (int)n_u, 64);
-    s->use_fused = ctx->generic_level == 0 && p->d_f32_exact && N >= 16 &&
+    s->use_v2 = ctx->generic_level == 0 && p->ND > 0 && p->D16 != nullptr && (n_c == 0 || p->Rtp != nullptr) &&
+                dmf::rowpass_v2_supported((int)S, (int)n_c, (int)n_u, 20) &&
+                dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
+    s->use_fused = (ctx->generic_level == 0 || ctx->generic_level == 4) && p->d_f32_exact && N >= 16 &&
                    dmf::rowpass_fused_supported((int)S, (int)n_c, (int)n_u) &&
                    dmf::u_phase_mfma_supported((int)S, (int)n_c, (int)n_u) && dmf::gram_u_supported((int)n_c, (int)n_u);
     if (s->u_path == 2 && !dmf::u_step_direct_supported((int)S, (int)n_c, (int)n_u)) {
@@ -728,6 +784,10 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
                              dmf::gram_u_slab_doubles(16, (int)S, (int)n_c, (int)n_u);  // + ragged tail rows
         if (spec > s->slab_doubles) s->slab_doubles = spec;
     }
+    if (s->use_v2) {
+        const int64_t bu = (int64_t)dmf::rowpass_v2_grid(N, (int)S) * n_u * S;
+        if (bu > s->slab_doubles) s->slab_doubles = bu;
+    }
     const size_t un = (size_t)N * n_u * sizeof(double), an = (size_t)K * S * sizeof(double);
     const size_t gbn = (size_t)(K + 1) * (K + 2) / 2 * S * sizeof(double);
     const int nb_alpha = (int)((S + 63) / 64);
@@ -739,7 +799,10 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->gb, gbn);
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->slab, (size_t)s->slab_doubles * sizeof(double));
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->partials, (size_t)2 * (nb_alpha + S) * sizeof(double));
-    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->u2_partials, 1024 * sizeof(double));
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->u2_partials, 4096 * sizeof(double));
+    if (e == hipSuccess && s->use_v2)
+        e = pool_alloc(ctx, (void**)&s->slab_i8,
+                       (size_t)dmf::gram_i8_slab_ints(N, p->SD, (int)n_c, (int)n_u, p->ND) * sizeof(int));
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->state, sizeof(SolverState));
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_state, sizeof(SolverState));
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->job_k, s->n_jobs * sizeof(short));
@@ -853,6 +916,7 @@ int dmf_solver_destroy(dmf_solver* s) {
     pool_free(ctx, s->alpha_prev);
     pool_free(ctx, s->gb);
     pool_free(ctx, s->slab);
+    pool_free(ctx, s->slab_i8);
     pool_free(ctx, s->partials);
     pool_free(ctx, s->u2_partials);
     pool_free(ctx, s->purity);
@@ -870,7 +934,11 @@ int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t
     const dmf_problem* p = s->p;
     const int S = (int)p->S, n_c = (int)p->n_c, n_u = (int)s->n_u, K = n_c + n_u;
     char row[160], gram[64];
-    if (s->use_fused && n_iter2 <= kSplitInnerSteps) {
+    if (s->use_v2 && n_iter2 <= kSplitInnerSteps && dmf::rowpass_v2_supported(S, n_c, n_u, (int)n_iter2)) {
+        snprintf(row, sizeof(row), "k_rowpass_v2<%d,%d> nw=%d grid=%d tail=%d", (n_c + 3) / 4, n_u, (S + 63) / 64,
+                 dmf::rowpass_v2_grid(p->N, S), (int)(p->N & 15));
+        snprintf(gram, sizeof(gram), "k_gram_i8<nd=%d>", p->ND);
+    } else if (s->use_fused && n_iter2 <= kSplitInnerSteps) {
         const int64_t n_full = p->N - (p->N & 15);
         snprintf(row, sizeof(row), "k_rowpass_fused<%d,%d> nw=%d grid=%d tail=%d", (n_c + 3) / 4, n_u, (S + 63) / 64,
                  dmf::rowpass_fused_grid(n_full, S), (int)(p->N & 15));

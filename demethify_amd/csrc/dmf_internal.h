@@ -56,6 +56,10 @@ hipError_t launch_convert_counts(const long long* src, double* dst, int64_t n, h
 hipError_t launch_max_f64(const double* x, int64_t n, double* scratch, double* out, hipStream_t st);
 // max |x - (double)(float)x| -> *out: 0 iff every element is exactly representable in f32
 hipError_t launch_f32_residual_max(const double* x, int64_t n, double* scratch, double* out, hipStream_t st);
+// max(x) if every element is a non-negative integer, +inf otherwise -> *out
+hipError_t launch_int_count_max(const double* x, int64_t n, double* scratch, double* out, hipStream_t st);
+// 0 if every element lies in [0, 1], 1 otherwise -> *out
+hipError_t launch_unit_range_check(const double* x, int64_t n, double* scratch, double* out, hipStream_t st);
 // sum of squares -> *out (device)
 hipError_t launch_sumsq_f64(const double* x, int64_t n, double* scratch, double* out,
                             const int* done_flag, hipStream_t st);
@@ -151,6 +155,27 @@ hipError_t launch_gram_mfma(const double* V, const double* D, const double* Rt, 
                             int n_c, int n_u, GramJobTable jobs, int n_dense, double* slab, int64_t slab_doubles,
                             const int* done_flag, int* ny_out, hipStream_t st);
 int64_t gram_mfma_slab_doubles(int64_t N, int S, int n_jobs);
+
+// ---- second-generation row pass (dmf_kernels_rowpass2.hip) + integer-matrix-core Gram (dmf_kernels_gram_i8.hip)
+// counts as u16 (D16[N16][SD], zero padded: N16 = N rounded up to 16, SD = S rounded up to 64) and as balanced 8-bit
+// digit planes in the MFMA B layout (Dt8[ND][ceil(N/32)][SD/32][32][32]); ND = 1 (d <= 127) or 2 (d <= 32639)
+hipError_t launch_build_counts_int(const double* D, int64_t N, int S, int ND, unsigned short* D16, int64_t N16, int SD,
+                                   signed char* Dt8, int64_t plane_stride, hipStream_t st);
+bool rowpass_v2_supported(int S, int n_c, int n_u, int n_iter2);
+int rowpass_v2_grid(int64_t N, int S);
+// u phase + b_u slab ([grid][n_u][S] doubles) + per-workgroup ||u||^2 shares in one read of V (f64) and D16
+hipError_t launch_rowpass_v2(const double* V, const unsigned short* D16, int SD, const double* Rtp, const double* alpha,
+                             double* u, double* u_prev, SolverState* state, int64_t N, int S, int n_c, int n_u,
+                             int n_iter2, int mode, double* slab, double* u2_partials, int* grid_out, hipStream_t st);
+bool gram_i8_supported(int n_c, int n_u, int ND, int64_t N, int SD);
+int64_t gram_i8_slab_ints(int64_t N, int SD, int n_c, int n_u, int ND);
+// exact cross / uu Gram entries: features p = (feat_a[p], feat_b[p]) over x = (Rt, u), i32 slab [ny][weights][slots][SD]
+hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, int ND, const double* Rt, const double* u,
+                          int64_t N, int n_c, int n_u, const short* feat_a, const short* feat_b, int NF, int* slab,
+                          const int* done_flag, int* ny_out, hipStream_t st);
+// gb rows of the u-dependent jobs from the i32 slab (jobs < NF) and the row pass's b_u slabs (jobs NF .. NF + n_u)
+hipError_t launch_gram_v2_reduce(const int* slab_i8, int ny, int ND, int NF, int SD, const double* slab_bu, int n_bu_slabs,
+                                 int n_u, int S, const int* dst_row, double* gb, const int* done_flag, hipStream_t st);
 
 // two percentiles over axis 0 of x[n][m] -> out0[m], out1[m] (out1 may be null); dmf_kernels_percentile.hip
 hipError_t launch_percentile_pair(const double* x, int64_t n, int64_t m, PercentilePlan p0, PercentilePlan p1,

@@ -20,6 +20,7 @@
 // `Rtp` is the problem's zero-padded copy of R_trunc (row stride 4 NKC).
 #include "dmf_device.h"
 #include "dmf_internal.h"
+#include "dmf_phaseb.h"
 
 namespace dmf {
 
@@ -60,64 +61,6 @@ constexpr int kTileRowDoubles = 66;  // V tile row: 64 samples + 16 B pad (f64)
 constexpr int kTileRowFloats = 68;   // D tile row: 64 samples + 16 B pad (f32: counts < 2^24 are exact)
 constexpr int kTileVBytes = 16 * kTileRowDoubles * 8;
 constexpr int kTileBytes = kTileVBytes + 16 * kTileRowFloats * 4;  // one column group, one buffer
-
-template <int CTRL>
-__device__ __forceinline__ double f_dpp_quad(double x) {
-    // mov_dpp, not update_dpp(0, ...): a quad permute has a source in every lane, and an "old" value would
-    // cost a v_mov per half to initialise the destination (8 extra instructions per inner step at n_u = 4)
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-
-template <int NU, int L>
-__device__ __forceinline__ double f_group_bcast(double x, int lane0) {
-    if constexpr (NU == 1) return x;
-    else if constexpr (NU == 2) return f_dpp_quad<(L) | (L << 2) | ((2 + L) << 4) | ((2 + L) << 6)>(x);
-    else if constexpr (NU == 4) return f_dpp_quad<L | (L << 2) | (L << 4) | (L << 6)>(x);
-    else return __shfl(x, lane0 + L, 64);
-}
-
-// sum_l base_l * Ms[l] over the NU lanes of a row group, as a balanced tree: phase B is one dependent
-// chain on the workgroup's critical path, so its depth (not its instruction count) is what costs
-template <int NU, int L0, int L1>
-__device__ __forceinline__ double f_dot_tree(double base, const double (&Ms)[NU], int lane0) {
-    if constexpr (L1 - L0 == 1) {
-        return f_group_bcast<NU, L0>(base, lane0) * Ms[L0];
-    } else {
-        constexpr int MID = (L0 + L1) / 2;
-        return f_dot_tree<NU, L0, MID>(base, Ms, lane0) + f_dot_tree<NU, MID, L1>(base, Ms, lane0);
-    }
-}
-
-// clip(a - b, 0, 1) in one instruction: the VOP3 clamp modifier clamps an FP result to [0, 1]
-// (np.clip(x, 0, 1) of deconvolution.py:88; a NaN would come out as 0 instead of NaN)
-__device__ __forceinline__ double f_sub_clamp01(double a, double b) {
-    double r;
-    asm("v_add_f64 %0, %1, -%2 clamp" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// clip(a * b + c, 0, 1) in one instruction: the VOP3 clamp modifier clamps an FP result to [0, 1]
-// (np.clip(x, 0, 1) of deconvolution.py:88; a NaN would come out as 0 instead of NaN)
-__device__ __forceinline__ double f_fma_clamp01(double a, double b, double c) {
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// clip(seed + sum_l x_l * Mn[l], 0, 1) over the NU lanes of a row group as one FMA chain whose last link clamps.
-// Under contention from the C waves of its SIMD the phase-B wave pays ~10 cycles per instruction issued,
-// dependent or not, so the instruction count (NU FMAs here against NU multiplies + NU adds for a balanced tree
-// and a separate clamp) matters more than the depth of the chain.
-template <int NU, int L = 0>
-__device__ __forceinline__ double f_step_chain(double acc, double x, const double (&Mn)[NU], int lane0) {
-    if constexpr (L == NU - 1) {
-        return f_fma_clamp01(f_group_bcast<NU, L>(x, lane0), Mn[L], acc);
-    } else {
-        return f_step_chain<NU, L + 1>(fma(f_group_bcast<NU, L>(x, lane0), Mn[L], acc), x, Mn, lane0);
-    }
-}
 
 // Team layout: a workgroup has 3 NW waves (NW = ceil(S / 64) column groups of 64 samples).
 //   A team  waves [0, NW): A wave w owns column group w for phase A (MFMA) and takes turns at phase B

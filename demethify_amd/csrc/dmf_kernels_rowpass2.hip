@@ -1,0 +1,417 @@
+// Row pass, second generation: the u phase of one outer iteration (deconvolution.py:81-90 / :157-164) plus the
+// part of the alpha phase's right-hand side that needs V (b_u = u^T (D * V)) in ONE read of V (f64) and of the
+// counts stored as u16 (D16: exact, 2 bytes per element instead of 8; built once per problem).  The u-dependent
+// Gram entries that need no V (cross = Rt^T diag(d) u, uu = u^T diag(d) u) are left to the integer matrix-core
+// kernel of dmf_kernels_gram_i8.hip, which reads the counts as 8-bit planes.
+//
+// Against the first-generation kernel (dmf_kernels_fused.hip) the FP64 work per element drops from 92 to 33 FMA
+// (phase C's 58 cross / uu products are gone), which is what that kernel was bound by; a workgroup is one wave per
+// 64-sample column group, holds its alpha-derived MFMA operands in registers instead of a 33 KB LDS copy, and needs
+// one 16-row tile buffer only, so several workgroups share a CU: while one of them runs the row-local inner iterations
+// (one wave, a dependent chain), the others keep the FP64 pipe busy with their contractions.
+//
+// Per 16-row block, per workgroup (waves = column groups):
+//   tile    prefetched global loads (V: 16 B per lane, two rows per instruction; D16: 16 B = 8 counts per lane)
+//           -> LDS tile of the wave's own column group (V f64, D as f32: exact for counts < 2^24)
+//   phase A FP64-MFMA contractions on the tile in the row-on-lane layout (as dmf_kernels_rowpass_mfma.hip):
+//           E = V - Rt a_known (16x16x4), c = a_unk (D*E)^T (4x4x4, 4 blocks), M = P D^T (16x16x4) -> partial c / M
+//   -- barrier X --
+//   phase B (one wave, round robin) sums the partials and runs the n_iter2 accelerated projected-gradient steps,
+//           lane = (row, unknown); u / u_ go to HBM and u to LDS
+//   -- barrier Y --
+//   phase C lane = sample: bu[j] += (d v) u_j over the 16 rows, in registers across all blocks of the workgroup
+// Rows beyond N in the last block read a clamped V row and zero counts (D16 is zero-padded to a multiple of 16 rows
+// and of 64 columns), so they add nothing; their u is never stored.
+//
+// Preconditions (checked by the launcher): S even, S <= 256, n_c <= 16, n_u <= 4, counts integral and <= 65535.
+#include "dmf_device.h"
+#include "dmf_internal.h"
+#include "dmf_phaseb.h"
+
+namespace dmf {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int kRowV = 66;  // V tile row: 64 samples + 16 B pad (f64)
+constexpr int kRowD = 68;  // D tile row: 64 samples + 16 B pad (f32)
+constexpr int kTileVBytes2 = 16 * kRowV * 8;
+constexpr int kTileBytes2 = kTileVBytes2 + 16 * kRowD * 4;  // one column group
+}  // namespace
+
+template <int NKC, int NU>
+__global__ __launch_bounds__(256, 2) void k_rowpass_v2(
+    const double* __restrict__ V, const unsigned short* __restrict__ D16, int SD, const double* __restrict__ Rtp,
+    const double* __restrict__ alpha, double* __restrict__ u, double* __restrict__ u_prev,
+    const SolverState* __restrict__ state, int64_t N, int S, int n_c, int n_iter2, int mode,
+    double* __restrict__ slab, double* __restrict__ u2_partials) {
+    static_assert(NU >= 1 && NU <= 4, "one phase-B pass per block, 4x4x4 MFMA for the c product");
+    constexpr int NCT = 4 * NKC;
+    constexpr int NP = NU * (NU + 1) / 2;
+    constexpr int NV = NU + NP;
+    extern __shared__ double lds_dyn[];
+    if (state->done) return;
+
+    const int NW = blockDim.x >> 6;  // column groups = waves
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wcol0 = wave * 64;
+
+    // LDS carve-up (doubles unless noted): beta[n_iter2 (even)] | ubuf[16][NU] | red[NW][NV][16] | u2[4] |
+    //   tiles[NW]{ V f64 [16][66], D f32 [16][68] }
+    double* __restrict__ beta_tab = lds_dyn;
+    double* __restrict__ ubuf = beta_tab + ((n_iter2 + 1) & ~1);
+    double* __restrict__ red = ubuf + 16 * NU;
+    double* __restrict__ u2red = red + NW * NV * 16;
+    char* __restrict__ tile = reinterpret_cast<char*>(u2red + 4) + (size_t)wave * kTileBytes2;
+    double* __restrict__ tileV = reinterpret_cast<double*>(tile);
+    float* __restrict__ tileD = reinterpret_cast<float*>(tile + kTileVBytes2);
+
+    if (threadIdx.x == 0) {
+        double a1 = state->a1, lw_prev = state->l_w_prev;
+        const double lw = state->l_w;
+        for (int t2 = 0; t2 < n_iter2; ++t2) {  // deconvolution.py:83-85
+            double beta;
+            momentum_step(a1, lw_prev, lw, beta);
+            beta_tab[t2] = beta;
+            lw_prev = lw;
+        }
+    }
+
+    // ---- alpha-derived MFMA A operands of this wave's four 16-sample strips, in registers for the whole launch
+    const int m16 = lane & 15, q = lane >> 4;
+    const int e_col = wcol0 + 4 * (m16 & 3) + (m16 >> 2);  // + 16 t: first product, m <-> sample
+    const int k_col = wcol0 + 4 * q;                        // + 16 t + r: k-step r, k = q <-> sample
+    double a1r[4][NKC > 0 ? NKC : 1];  // -alpha_known[k = 4 kc + q][sample]
+    double a2r[4][4];                  // alpha_unk[m16 & 3][sample] (c product, 4x4x4: block = 4 rows, i = unknown)
+    double ppr[4][4];                  // alpha_unk[j] * alpha_unk[l] of pair p = m16 (M product)
+    {
+        int pj = 0, pl = 0;
+        while ((pl + 1) * (pl + 2) / 2 <= m16) ++pl;
+        pj = m16 - pl * (pl + 1) / 2;
+        const bool pair_ok = m16 < NP;
+        const bool a2_ok = (m16 & 3) < NU;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) {
+                const int row = kc * 4 + q, col = e_col + 16 * t;
+                a1r[t][kc] = (row < n_c && col < S) ? -alpha[(int64_t)row * S + col] : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = k_col + 16 * t + r;
+                const bool in = col < S;
+                a2r[t][r] = (in && a2_ok) ? alpha[(int64_t)(n_c + (m16 & 3)) * S + col] : 0.0;
+                ppr[t][r] = (in && pair_ok) ? alpha[(int64_t)(n_c + pj) * S + col] * alpha[(int64_t)(n_c + pl) * S + col] : 0.0;
+            }
+        }
+    }
+    __syncthreads();  // beta_tab
+
+    const int64_t nblk = (N + 15) / 16;
+    const int nk = (int)((nblk - blockIdx.x + gridDim.x - 1) / gridDim.x);  // blocks of this workgroup
+    const double inv_lw = 1.0 / state->l_w;  // x / l_w as x * (1 / l_w): <= 1 ulp from the division
+
+    // global -> register staging: V load i covers rows 2i, 2i+1 (lane -> row half, 2 samples);
+    // D16 load i covers rows 8i .. 8i+7 (lane -> row lane >> 3, 8 samples)
+    const int ld_row = lane >> 5;
+    const int ld_col = (lane & 31) * 2;
+    int ld_gcol = wcol0 + ld_col;
+    if (ld_gcol > S - 2) ld_gcol = S - 2;  // ragged last column group: clamped samples meet zero counts
+    const int d_row = lane >> 3, d_col = (lane & 7) * 8;
+    v2d pv[8];
+    v4u pd[2];
+    double nrt[NKC > 0 ? NKC : 1];
+    auto prefetch = [&](int64_t blk) {
+        const int64_t r0 = blk * 16;
+        if (r0 + 16 <= N) {  // (wave-uniform)
+            const double* __restrict__ rb = Rtp + r0 * NCT + m16 * NCT + q;
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) nrt[kc] = rb[kc * 4];
+            const double* __restrict__ vb = V + r0 * S + ld_row * S + ld_gcol;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pv[i] = *reinterpret_cast<const v2d*>(vb + (2 * i) * S);
+        } else {  // last, partial block: rows beyond N read row N - 1 (their counts are zero)
+            const int64_t rr = r0 + m16 < N ? r0 + m16 : N - 1;
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) nrt[kc] = Rtp[rr * NCT + kc * 4 + q];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t rv = r0 + 2 * i + ld_row < N ? r0 + 2 * i + ld_row : N - 1;
+                pv[i] = *reinterpret_cast<const v2d*>(V + rv * S + ld_gcol);
+            }
+        }
+        const unsigned short* __restrict__ db = D16 + (r0 + d_row) * SD + wcol0 + d_col;
+        pd[0] = *reinterpret_cast<const v4u*>(db);
+        pd[1] = *reinterpret_cast<const v4u*>(db + (int64_t)8 * SD);
+    };
+    if (nk > 0) prefetch(blockIdx.x);
+
+    double bu[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) bu[j] = 0.0;
+    double u2_acc = 0.0;
+    // 64 / NU >= 16 rows per wave: one phase-B pass covers the block
+    const int rl = lane / NU, jb = lane - rl * NU;
+    const bool b_lane = rl < 16;
+
+    for (int s = 0; s < nk; ++s) {
+        const int64_t blk = blockIdx.x + (int64_t)s * gridDim.x;
+        const int64_t row0 = blk * 16;
+        // ---- tile store (waits for the prefetched loads)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<v2d*>(tileV + (2 * i + ld_row) * kRowV + ld_col) = pv[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float* __restrict__ dst = tileD + (8 * i + d_row) * kRowD + d_col;
+            const v4u w = pd[i];
+            *reinterpret_cast<v4f*>(dst) = v4f{(float)(w.x & 0xFFFFu), (float)(w.x >> 16), (float)(w.y & 0xFFFFu), (float)(w.y >> 16)};
+            *reinterpret_cast<v4f*>(dst + 4) = v4f{(float)(w.z & 0xFFFFu), (float)(w.z >> 16), (float)(w.w & 0xFFFFu), (float)(w.w >> 16)};
+        }
+        double rtop[NKC > 0 ? NKC : 1];
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) rtop[kc] = nrt[kc];  // B operand of the first product: Rt^T[k = 4 kc + q][n = row]
+        // the wave that will run this block's inner iterations fetches its u / u_ now
+        const bool my_turn = wave == s % NW;
+        const bool ok = b_lane && row0 + rl < N;
+        const int64_t gi = ok ? (row0 + rl) * NU + jb : 0;
+        // (unconditional on purpose: loads under a branch make the compiler's s_waitcnt placement pessimistic)
+        const double uu0 = u[gi];
+        const double up0 = u_prev[gi];
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- phase A: strips of 16 samples; the LDS reads of strip t + 1 are issued before the MFMAs of strip t,
+        // and the E chain of strip t + 1 is slotted between the c / M MFMAs of strip t (a dependent FP64 MFMA
+        // stalls behind its producer)
+        struct Strip {
+            v2d v01, v23;
+            v4f df;
+        };
+        auto load_strip = [&](int t, Strip& R) {
+            const double* __restrict__ tv = tileV + m16 * kRowV + t * 16 + 4 * q;
+            R.v01 = *reinterpret_cast<const v2d*>(tv);
+            R.v23 = *reinterpret_cast<const v2d*>(tv + 2);
+            R.df = *reinterpret_cast<const v4f*>(tileD + m16 * kRowD + t * 16 + 4 * q);
+        };
+        double csm0 = 0.0, csm1 = 0.0;  // c[unknown q][row m16], one double per lane
+        v4d macc = {0.0, 0.0, 0.0, 0.0}, macc1 = macc;
+        auto e_init = [&](const Strip& R) { return v4d{R.v01.x, R.v01.y, R.v23.x, R.v23.y}; };
+        auto run_strip = [&](const Strip& R, v4d e, const Strip& Rn, const double (&a1n)[NKC > 0 ? NKC : 1],
+                             const double (&a2)[4], const double (&pp)[4], bool has_next) {
+            const v4d d = {(double)R.df.x, (double)R.df.y, (double)R.df.z, (double)R.df.w};
+            const v4d w = d * e;
+            v4d en = e_init(Rn);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r & 1) csm1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[r], w[r], csm1, 0, 0, 0);
+                else csm0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[r], w[r], csm0, 0, 0, 0);
+                if (r & 1) macc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pp[r], d[r], macc1, 0, 0, 0);
+                else macc = __builtin_amdgcn_mfma_f64_16x16x4f64(pp[r], d[r], macc, 0, 0, 0);
+                if (has_next && r < NKC) en = __builtin_amdgcn_mfma_f64_16x16x4f64(a1n[r], rtop[r], en, 0, 0, 0);
+            }
+            return en;
+        };
+        Strip sa, sb;
+        load_strip(0, sa);
+        load_strip(1, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        v4d e0 = e_init(sa);
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) e0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1r[0][kc], rtop[kc], e0, 0, 0, 0);
+        const v4d e1 = run_strip(sa, e0, sb, a1r[1], a2r[0], ppr[0], true);
+        load_strip(2, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        const v4d e2 = run_strip(sb, e1, sa, a1r[2], a2r[1], ppr[1], true);
+        load_strip(3, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        const v4d e3 = run_strip(sa, e2, sb, a1r[3], a2r[2], ppr[2], true);
+        (void)run_strip(sb, e3, sb, a1r[3], a2r[3], ppr[3], false);
+        macc += macc1;
+        const double csm = csm0 + csm1;
+        // the next block's global loads: their staging registers were free during phase A, and the loads have
+        // phases B and C (and the other workgroups' turns on this CU) to land
+        if (s + 1 < nk) prefetch(blk + gridDim.x);
+        {
+            double* __restrict__ mine = red + (size_t)wave * NV * 16;
+            if (q < NU) mine[q * 16 + m16] = csm;  // c[unknown q][row m16]
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int p = q + 4 * rr;  // C layout of the 16x16x4 tile: row (= pair) q + 4 reg, col = m16
+                if (p < NP) mine[(NU + p) * 16 + m16] = macc[rr];
+            }
+        }
+        __syncthreads();  // ---- barrier X
+
+        // ---- phase B: row-local inner iterations, lane = (row, unknown j); c and M pre-scaled by 1 / l_w
+        if (my_turn) {
+            __builtin_amdgcn_s_setprio(3);  // a dependent chain on the workgroup's critical path
+            const int lane0 = lane - jb;
+            const int rlc = rl < 16 ? rl : 15;
+            double cj = 0.0, Ms[NU];
+#pragma unroll
+            for (int l = 0; l < NU; ++l) Ms[l] = 0.0;
+            for (int w = 0; w < NW; ++w) {
+                const double* __restrict__ part = red + (size_t)w * NV * 16;
+                cj += part[jb * 16 + rlc];
+#pragma unroll
+                for (int l = 0; l < NU; ++l) {
+                    const int p = l <= jb ? tri(l, jb) : tri(jb, l);
+                    Ms[l] += part[(NU + p) * 16 + rlc];
+                }
+            }
+            cj *= inv_lw;
+#pragma unroll
+            for (int l = 0; l < NU; ++l) Ms[l] *= -inv_lw;  // the chain below adds -M x
+            double uu = uu0, up = up0;
+            // The momentum coefficients ride in a VGPR (lane t holds beta_t) and reach the loop through
+            // v_readlane: an LDS read here would sit on the dependent chain every step.
+            for (int t0 = 0; t0 < n_iter2; t0 += 64) {
+                const int tl = t0 + lane < n_iter2 ? t0 + lane : n_iter2 - 1;
+                const double bvec = beta_tab[tl];
+                const int b_lo = __double2loint(bvec), b_hi = __double2hiint(bvec);
+                const int t_end = n_iter2 - t0 < 64 ? n_iter2 - t0 : 64;
+                if (mode == 1) {  // deconvolution.py:163: gradient at the previous iterate
+#pragma unroll 2
+                    for (int t2 = 0; t2 < t_end; ++t2) {
+                        const double beta = __hiloint2double(__builtin_amdgcn_readlane(b_hi, t2),
+                                                             __builtin_amdgcn_readlane(b_lo, t2));
+                        const double ut = fma(beta, uu - up, uu);
+                        up = uu;
+                        uu = f_step_chain<NU>(ut + cj, up, Ms, lane0);
+                    }
+                } else {          // deconvolution.py:88: gradient at the extrapolated point
+#pragma unroll 2
+                    for (int t2 = 0; t2 < t_end; ++t2) {
+                        const double beta = __hiloint2double(__builtin_amdgcn_readlane(b_hi, t2),
+                                                             __builtin_amdgcn_readlane(b_lo, t2));
+                        const double ut = fma(beta, uu - up, uu);
+                        up = uu;
+                        uu = f_step_chain<NU>(ut + cj, ut, Ms, lane0);
+                    }
+                }
+            }
+            if (b_lane) ubuf[rl * NU + jb] = ok ? uu : 0.0;  // rows beyond N: phase C multiplies them by zero counts
+            if (ok) {
+                u[gi] = uu;
+                u_prev[gi] = up;
+                u2_acc = fma(uu, uu, u2_acc);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();  // ---- barrier Y
+
+        // ---- phase C: lane = sample of this wave's column group; bu[j] += (d v) u_j over the block's rows
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double t = (double)tileD[r * kRowD + lane] * tileV[r * kRowV + lane];
+            if constexpr ((NU & 1) == 0) {
+#pragma unroll
+                for (int j = 0; j < NU; j += 2) {  // 16-B broadcast reads
+                    const v2d two = *reinterpret_cast<const v2d*>(ubuf + r * NU + j);
+                    bu[j] = fma(t, two.x, bu[j]);
+                    bu[j + 1] = fma(t, two.y, bu[j + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) bu[j] = fma(t, ubuf[r * NU + j], bu[j]);
+            }
+        }
+        // (the next iteration's tile store touches this wave's own tile only; ubuf and red are rewritten behind
+        // the next barrier X / by phase A after this wave's own phase C)
+    }
+
+    // ---- b_u slab of this workgroup [NU][S] and its share of ||u||_F^2
+    const int sC = wcol0 + lane;
+    if (sC < S) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) slab[((int64_t)blockIdx.x * NU + j) * S + sC] = bu[j];
+    }
+    const double w2 = wave_sum(u2_acc);
+    if (lane == 0) u2red[wave] = w2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < NW; ++w) tot += u2red[w];
+        u2_partials[blockIdx.x] = tot;
+    }
+}
+
+size_t rowpass_v2_lds_bytes(int S, int n_u, int n_iter2) {
+    const int NW = (S + 63) / 64;
+    const int nv = n_u + n_u * (n_u + 1) / 2;
+    const size_t doubles = (size_t)((n_iter2 + 1) & ~1) + 16 * n_u + (size_t)NW * nv * 16 + 4;
+    return doubles * sizeof(double) + (size_t)NW * kTileBytes2;
+}
+
+bool rowpass_v2_supported(int S, int n_c, int n_u, int n_iter2) {
+    if ((S & 1) != 0 || S < 2 || S > 256 || n_c > 16 || n_u < 1 || n_u > 4) return false;
+    return rowpass_v2_lds_bytes(S, n_u, n_iter2) <= 64 * 1024;
+}
+
+int rowpass_v2_grid(int64_t N, int S) {
+    const int NW = (S + 63) / 64;
+    const int per_cu = 8 / NW;  // two waves per SIMD: NW = 4 -> 2, 3 -> 2, 2 -> 4, 1 -> 8 workgroups per CU
+    const int64_t nblk = (N + 15) / 16;
+    const int64_t g = 256 * per_cu;
+    return (int)(nblk < g ? nblk : g);
+}
+
+template <int NKC, int NU>
+static hipError_t launch_v2_t(const double* V, const unsigned short* D16, int SD, const double* Rtp, const double* alpha,
+                              double* u, double* u_prev, SolverState* state, int64_t N, int S, int n_c, int n_iter2,
+                              int mode, double* slab, double* u2_partials, int* grid_out, hipStream_t st) {
+    const int NW = (S + 63) / 64;
+    const size_t lds = rowpass_v2_lds_bytes(S, NU, n_iter2);
+    if (lds > 64 * 1024 || N < 1 || SD < NW * 64 || (SD & 7) != 0) return hipErrorInvalidValue;
+    static bool lds_limit_raised[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (lds > 48 * 1024 && !lds_limit_raised[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_rowpass_v2<NKC, NU>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           64 * 1024);
+        if (e != hipSuccess) return e;
+        lds_limit_raised[dev] = true;
+    }
+    const int grid = rowpass_v2_grid(N, S);
+    *grid_out = grid;
+    hipLaunchKernelGGL((k_rowpass_v2<NKC, NU>), dim3(grid), dim3(NW * 64), lds, st, V, D16, SD, Rtp, alpha, u, u_prev,
+                       state, N, S, n_c, n_iter2, mode, slab, u2_partials);
+    return hipGetLastError();
+}
+
+template <int NKC>
+static hipError_t launch_v2_nkc(int n_u, const double* V, const unsigned short* D16, int SD, const double* Rtp,
+                                const double* alpha, double* u, double* u_prev, SolverState* state, int64_t N, int S,
+                                int n_c, int n_iter2, int mode, double* slab, double* u2_partials, int* grid_out,
+                                hipStream_t st) {
+    switch (n_u) {
+#define DMF_CASE(NU_)                                                                                            \
+    case NU_:                                                                                                    \
+        return launch_v2_t<NKC, NU_>(V, D16, SD, Rtp, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, slab, \
+                                     u2_partials, grid_out, st);
+        DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4)
+#undef DMF_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_rowpass_v2(const double* V, const unsigned short* D16, int SD, const double* Rtp, const double* alpha,
+                             double* u, double* u_prev, SolverState* state, int64_t N, int S, int n_c, int n_u,
+                             int n_iter2, int mode, double* slab, double* u2_partials, int* grid_out, hipStream_t st) {
+    switch ((n_c + 3) / 4) {
+#define DMF_NKC(X)                                                                                                \
+    case X:                                                                                                       \
+        return launch_v2_nkc<X>(n_u, V, D16, SD, Rtp, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, slab, \
+                                u2_partials, grid_out, st);
+        DMF_NKC(0) DMF_NKC(1) DMF_NKC(2) DMF_NKC(3) DMF_NKC(4)
+#undef DMF_NKC
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace dmf

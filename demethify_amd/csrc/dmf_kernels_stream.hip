@@ -22,6 +22,7 @@ hipError_t launch_convert_counts(const long long* src, double* dst, int64_t n, h
 }
 
 // MODE 0: max(x)   MODE 1: sum(x^2)   MODE 2: max |x - (double)(float)x|  (is x exact in f32?)
+// MODE 3: max(x) if every x is a non-negative integer, +inf otherwise   MODE 4: 0 if every x lies in [0, 1], else 1
 template <int MODE>
 __global__ __launch_bounds__(256) void k_reduce_partial(const double* __restrict__ x, int64_t n,
                                                         double* __restrict__ partial,
@@ -35,7 +36,9 @@ __global__ __launch_bounds__(256) void k_reduce_partial(const double* __restrict
         const double v = x[i];
         if (MODE == 1) acc = fma(v, v, acc);
         else if (MODE == 0) acc = fmax(acc, v);
-        else acc = fmax(acc, fabs(v - (double)(float)v));
+        else if (MODE == 2) acc = fmax(acc, fabs(v - (double)(float)v));
+        else if (MODE == 3) acc = fmax(acc, (v >= 0.0 && v == rint(v)) ? v : INFINITY);
+        else acc = fmax(acc, (v >= 0.0 && v <= 1.0) ? 0.0 : 1.0);
     }
     const double tot = MODE == 1 ? block_sum<256>(acc, red) : block_max<256>(acc, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
@@ -73,6 +76,20 @@ hipError_t launch_max_f64(const double* x, int64_t n, double* scratch, double* o
 hipError_t launch_f32_residual_max(const double* x, int64_t n, double* scratch, double* out, hipStream_t st) {
     const int nb = reduce_blocks(n);
     hipLaunchKernelGGL(k_reduce_partial<2>, dim3(nb), dim3(256), 0, st, x, n, scratch, (const int*)nullptr);
+    hipLaunchKernelGGL(k_reduce_final<0>, dim3(1), dim3(256), 0, st, scratch, nb, out, (const int*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_int_count_max(const double* x, int64_t n, double* scratch, double* out, hipStream_t st) {
+    const int nb = reduce_blocks(n);
+    hipLaunchKernelGGL(k_reduce_partial<3>, dim3(nb), dim3(256), 0, st, x, n, scratch, (const int*)nullptr);
+    hipLaunchKernelGGL(k_reduce_final<0>, dim3(1), dim3(256), 0, st, scratch, nb, out, (const int*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_unit_range_check(const double* x, int64_t n, double* scratch, double* out, hipStream_t st) {
+    const int nb = reduce_blocks(n);
+    hipLaunchKernelGGL(k_reduce_partial<4>, dim3(nb), dim3(256), 0, st, x, n, scratch, (const int*)nullptr);
     hipLaunchKernelGGL(k_reduce_final<0>, dim3(1), dim3(256), 0, st, scratch, nb, out, (const int*)nullptr);
     return hipGetLastError();
 }

@@ -70,9 +70,9 @@ class Context:
         L.check(self._lib.dmf_context_set_profiling(self._h, mode), "dmf_context_set_profiling")
 
     def set_generic(self, level: int):
-        """Kernel selection for tests: 0 fastest (fused FP64-MFMA row pass), 1 any-shape Gram-form kernels,
-        2 schedule-faithful one-launch-per-inner-step kernels, 3 the unfused MFMA row pass + one-pass Gram
-        pair that level 0 falls back to."""
+        """Kernel selection for tests: 0 fastest (u16-count row pass + integer-MFMA Gram, falling back to level 4,
+        then 3), 1 any-shape Gram-form kernels, 2 schedule-faithful one-launch-per-inner-step kernels, 3 the unfused
+        MFMA row pass + one-pass Gram pair, 4 the first-generation fused FP64 row pass.  Set before creating Problems."""
         L.check(self._lib.dmf_context_set_generic(self._h, int(level)), "dmf_context_set_generic")
 
     def reset_kernel_time(self):

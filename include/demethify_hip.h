@@ -78,9 +78,11 @@ int dmf_context_synchronize(dmf_context* ctx);
 int dmf_context_set_profiling(dmf_context* ctx, int enabled);
 int dmf_context_kernel_time(dmf_context* ctx, int family, double* total_ms, int64_t* launches);
 int dmf_context_reset_kernel_time(dmf_context* ctx);
-/* Kernel selection, for tests: 0 = fastest available (fused FP64-MFMA row pass), 1 = any-shape
- * Gram-form kernels without MFMA, 2 = schedule-faithful one-launch-per-inner-step, 3 = the unfused
- * pair (FP64-MFMA u-phase row pass + one-pass Gram) that level 0 falls back to. */
+/* Kernel selection, for tests: 0 = fastest available (row pass on u16 counts + exact integer-matrix-core Gram,
+ * else the first-generation fused FP64 row pass, else the unfused pair), 1 = any-shape Gram-form kernels without
+ * MFMA, 2 = schedule-faithful one-launch-per-inner-step, 3 = the unfused pair (FP64-MFMA u-phase row pass + one-pass
+ * Gram), 4 = the first-generation fused FP64 row pass (level 0's fall-back for counts beyond 32639 or reference
+ * profiles outside [0, 1]).  Set it before creating problems: the integer count copies are built at level 0 only. */
 int dmf_context_set_generic(dmf_context* ctx, int level);
 
 /* ---- problem: V, D, Rt resident in HBM + the per-problem constants ----------------------

@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 
 TIGHT = 1e-8
 
-# (N, S, n_c, n_u, T1, what the case is for)
+# (N, S, n_c, n_u, T1, what the case is for); every case runs on the second-generation pair (level 0: k_rowpass_v2 on
+# u16 counts + the integer-matrix-core Gram) and on the first-generation fused FP64 kernel (level 4: level 0's
+# fall-back for counts beyond 32639 or reference profiles outside [0, 1])
 FUSED_CASES = [
     (4096 + 5, 256, 12, 4, 4, "<3,4> nw=4 (the bench's instantiation), one block per workgroup, ragged 5-row tail"),
     (9600 + 5, 256, 12, 4, 3, "<3,4> nw=4, 2-3 blocks per workgroup: the persistent loop and the tile double buffer"),
@@ -37,26 +39,86 @@ def _oracle(V, D, Rt, n_c, n_u, T1, seed):
     return u0, a0, wu, wa
 
 
-@pytest.mark.parametrize("N,S,n_c,n_u,T1,why", FUSED_CASES)
-def test_fused_instantiations_against_oracle(ctx, N, S, n_c, n_u, T1, why):
-    from demethify_amd import _lib as L
+def _solve_at_level(ctx, level, V, D, Rt, u0, a0, mode, T1, expect):
+    """(u, alpha, Gram-form cost, direct cost, path) with the kernel selection `level`; the Problem is created under
+    that level because the integer count copies of the second-generation kernels are built at level 0 only."""
     from demethify_amd.device import Problem, Solver
+
+    ctx.set_generic(level)
+    try:
+        with Problem(ctx, V, D, Rt) as p, Solver(p, u0, a0, mode) as s:
+            path = s.describe(20)
+            for token in expect:
+                assert token in path, (token, path)
+            it, _ = s.step(T1, 20, 0.0)
+            assert it == T1
+            u, alpha, cost, _ = s.get()
+            direct = s.direct_cost()
+            assert direct == p.cost(u, alpha)  # the device-resident and the host-array entry points agree bit for bit
+    finally:
+        ctx.set_generic(0)
+    return u, alpha, cost, direct, path
+
+
+@pytest.mark.parametrize("level,kernel", [(0, "k_rowpass_v2"), (4, "k_rowpass_fused")])
+@pytest.mark.parametrize("N,S,n_c,n_u,T1,why", FUSED_CASES)
+def test_fused_instantiations_against_oracle(ctx, N, S, n_c, n_u, T1, why, level, kernel):
+    from demethify_amd import _lib as L
 
     V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=31, depth=40)
     u0, a0, wu, wa = _oracle(V, D, Rt, n_c, n_u, T1, seed=1)
     mode = L.DMF_MODE_PARTIAL if n_c else L.DMF_MODE_UNSUPERVISED
-    with Problem(ctx, V, D, Rt if n_c else None) as p, Solver(p, u0, a0, mode) as s:
-        path = s.describe(20)
-        assert f"<{(n_c + 3) // 4},{n_u}>" in path and f"nw={(S + 63) // 64}" in path and f"tail={N % 16}" in path, path
-        assert "fused" in path.split("rowpass=")[1].split()[0], path
-        it, _ = s.step(T1, 20, 0.0)
-        u, alpha, cost, _ = s.get()
-        direct = p.cost(u, alpha)
-    assert it == T1
+    expect = [f"rowpass={kernel}<{(n_c + 3) // 4},{n_u}>", f"nw={(S + 63) // 64}", f"tail={N % 16}"]
+    if level == 0:
+        expect.append("gram=k_gram_i8<nd=1>")
+    u, alpha, cost, direct, _ = _solve_at_level(ctx, level, V, D, Rt if n_c else None, u0, a0, mode, T1, expect)
     assert rel_err(alpha, wa) < TIGHT and np.abs(alpha - wa).max() < TIGHT, why
     assert np.abs(u - wu).max() < TIGHT, why
     want = osol.weighted_cost(V, np.c_[Rt, wu] if n_c else wu, wa, D)
     assert cost == pytest.approx(want, rel=1e-9) and direct == pytest.approx(want, rel=1e-11)
+
+
+# shapes only the second-generation pair takes (the first-generation kernel needs S % 4 == 0 and N >= 16)
+V2_CASES = [
+    (5, 6, 2, 1, 5, 40, "fewer than 16 rows: one partial block"),
+    (100, 130, 4, 2, 4, 40, "S = 2 mod 4, ragged third column group (clamped V columns, zero-padded counts)"),
+    (1000, 64, 3, 2, 4, 3000, "counts up to ~3300: two balanced 8-bit digits (nd=2)"),
+    (777, 30, 0, 1, 4, 40, "one feature only (u u), no known types"),
+    (2000, 256, 16, 4, 3, 60, "74 features: two launches of the integer Gram (64 + 10)"),
+    (1500, 64, 16, 4, 3, 2500, "nd=2 with 74 features: three launches of 32"),
+]
+
+
+@pytest.mark.parametrize("N,S,n_c,n_u,T1,depth,why", V2_CASES)
+def test_second_generation_shapes_against_oracle(ctx, N, S, n_c, n_u, T1, depth, why):
+    from demethify_amd import _lib as L
+
+    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=17, depth=depth)
+    D[::7, ::3] = 0  # zero coverage (what --fillna produces)
+    V = np.where(D == 0, 0.0, V)
+    u0, a0, wu, wa = _oracle(V, D, Rt, n_c, n_u, T1, seed=2)
+    mode = L.DMF_MODE_PARTIAL if n_c else L.DMF_MODE_UNSUPERVISED
+    nd = 1 if D.max() <= 127 else 2
+    u, alpha, cost, direct, _ = _solve_at_level(ctx, 0, V, D, Rt if n_c else None, u0, a0, mode, T1,
+                                                ["rowpass=k_rowpass_v2<", f"gram=k_gram_i8<nd={nd}>"])
+    assert rel_err(alpha, wa) < TIGHT and np.abs(alpha - wa).max() < TIGHT, why
+    assert np.abs(u - wu).max() < TIGHT, why
+    want = osol.weighted_cost(V, np.c_[Rt, wu] if n_c else wu, wa, D)
+    assert cost == pytest.approx(want, rel=1e-9) and direct == pytest.approx(want, rel=1e-11)
+
+
+def test_second_generation_preconditions_fall_back(ctx):
+    """Counts beyond two 8-bit digits, fractional weights or reference profiles outside [0, 1] must not reach the
+    integer kernels: the first-generation / unfused FP64 kernels take over and parity holds."""
+    from demethify_amd import _lib as L
+
+    V, D, Rt = osol.synthetic_problem(640, 32, 4, 2, seed=23, depth=40)
+    cases = {"big counts": (V, D * 1000, Rt), "reference above 1": (V, D, Rt * 1.5)}
+    for name, (v, d, rt) in cases.items():
+        u0, a0, wu, wa = _oracle(v, d, rt, 4, 2, 3, seed=1)
+        u, alpha, _, _, path = _solve_at_level(ctx, 0, v, d, rt, u0, a0, L.DMF_MODE_PARTIAL, 3, ["rowpass="])
+        assert "k_rowpass_v2" not in path and "k_gram_i8" not in path, (name, path)
+        assert rel_err(alpha, wa) < TIGHT and np.abs(u - wu).max() < TIGHT, name
 
 
 def test_headline_columns_at_oracle_size(ctx):
@@ -69,7 +131,7 @@ def test_headline_columns_at_oracle_size(ctx):
     V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=0, depth=50)
     u0, a0, wu, wa = _oracle(V, D, Rt, n_c, n_u, 3, seed=1)
     with Problem(ctx, V, D, Rt) as p, Solver(p, u0, a0, L.DMF_MODE_PARTIAL) as s:
-        assert "<3,4>" in s.describe(20) and "nw=4" in s.describe(20)
+        assert "k_rowpass_v2<3,4>" in s.describe(20) and "nw=4" in s.describe(20) and "k_gram_i8<nd=1>" in s.describe(20)
         s.step(3, 20, 0.0)
         u, alpha, cost, _ = s.get()
     assert rel_err(alpha, wa) < TIGHT and np.abs(u - wu).max() < TIGHT
