@@ -92,7 +92,8 @@ struct dmf_solver {
     int64_t beta_cap = 0;  // shapes beyond the lane-per-sample kernel's registers: MFMA Gram
     bool use_fused = false;      // first-generation fused row pass (counts as f64 in HBM, FP64 Gram in the kernel)
     bool use_v2 = false;         // second generation: u16 counts in the row pass + integer-MFMA Gram
-    int* slab_i8 = nullptr;      // i32 partial sums of the integer Gram
+    long long* slab_i8 = nullptr;   // i64 partial sums of the integer Gram (one slab per row range)
+    long long* acc_i8 = nullptr;    // reduction scratch of the integer Gram (kept zero between iterations)
     double* purity = nullptr;  // S per-sample known-block masses: set => Frank-Wolfe alpha phase
     double* u2_partials = nullptr;
     double *u = nullptr, *u_prev = nullptr, *u_next = nullptr;
@@ -427,10 +428,10 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
         HIP_TRY(dmf::launch_finish_u_norm(s->u2_partials, grid, s->state, ctx->stream));
         {
             FamilyScope scope(ctx, DMF_KERNEL_GRAM);
-            HIP_TRY(dmf::launch_gram_i8(p->Dt8, p->plane_stride, p->SD, p->ND, p->Rt, s->u, p->N, n_c, n_u, s->job_k,
+            HIP_TRY(dmf::launch_gram_i8(p->Dt8, p->plane_stride, p->SD, p->ND, p->Rtp, s->u, p->N, n_c, n_u, s->job_k,
                                         s->job_l, nf, s->slab_i8, &s->state->done, &ny, ctx->stream));
-            HIP_TRY(dmf::launch_gram_v2_reduce(s->slab_i8, ny, p->ND, nf, p->SD, s->slab, grid, n_u, S, s->job_dst, s->gb,
-                                               &s->state->done, ctx->stream));
+            HIP_TRY(dmf::launch_gram_v2_reduce(s->slab_i8, ny, nf, p->SD, s->slab, grid, n_u, S, s->acc_i8, s->job_dst,
+                                               s->gb, &s->state->done, ctx->stream));
         }
         DMF_TRY(enqueue_alpha_phase(s, n_iter2));
         return DMF_OK;
@@ -749,6 +750,7 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     s->use_gram_mfma = fast && !s->use_gram_spec;
     s->use_u_big = fast && s->u_path != 0 && dmf::u_phase_big_supported((int)S, (int)n_c, (int)n_u, 64);
     s->use_v2 = ctx->generic_level == 0 && p->ND > 0 && p->D16 != nullptr && (n_c == 0 || p->Rtp != nullptr) &&
+                (reinterpret_cast<uintptr_t>(p->V) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0 &&
                 dmf::rowpass_v2_supported((int)S, (int)n_c, (int)n_u, 20) &&
                 dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
     s->use_fused = (ctx->generic_level == 0 || ctx->generic_level == 4) && p->d_f32_exact && N >= 16 &&
@@ -789,11 +791,12 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
         if (bu > s->slab_doubles) s->slab_doubles = bu;
     }
     const size_t un = (size_t)N * n_u * sizeof(double), an = (size_t)K * S * sizeof(double);
+    const size_t un_alloc = (un + 15) & ~(size_t)15;  // the integer Gram kernel fetches u in 16-byte pieces
     const size_t gbn = (size_t)(K + 1) * (K + 2) / 2 * S * sizeof(double);
     const int nb_alpha = (int)((S + 63) / 64);
-    hipError_t e = pool_alloc(ctx, (void**)&s->u, un);
-    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->u_prev, un);
-    if (e == hipSuccess && s->u_path == 2) e = pool_alloc(ctx, (void**)&s->u_next, un);
+    hipError_t e = pool_alloc(ctx, (void**)&s->u, un_alloc);
+    if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->u_prev, un_alloc);
+    if (e == hipSuccess && s->u_path == 2) e = pool_alloc(ctx, (void**)&s->u_next, un_alloc);
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->alpha, an);
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->alpha_prev, an);
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->gb, gbn);
@@ -801,8 +804,12 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->partials, (size_t)2 * (nb_alpha + S) * sizeof(double));
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->u2_partials, 4096 * sizeof(double));
     if (e == hipSuccess && s->use_v2)
-        e = pool_alloc(ctx, (void**)&s->slab_i8,
-                       (size_t)dmf::gram_i8_slab_ints(N, p->SD, (int)n_c, (int)n_u, p->ND) * sizeof(int));
+        e = pool_alloc(ctx, (void**)&s->slab_i8, (size_t)dmf::gram_i8_slab_words(N, p->SD, (int)n_c, (int)n_u) * sizeof(long long));
+    if (e == hipSuccess && s->use_v2) {
+        const size_t bytes = (size_t)dmf::gram_i8_acc_words((int)S, (int)n_c, (int)n_u) * sizeof(long long);
+        e = pool_alloc(ctx, (void**)&s->acc_i8, bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(s->acc_i8, 0, bytes, ctx->stream);
+    }
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->state, sizeof(SolverState));
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_state, sizeof(SolverState));
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->job_k, s->n_jobs * sizeof(short));
@@ -917,6 +924,7 @@ int dmf_solver_destroy(dmf_solver* s) {
     pool_free(ctx, s->gb);
     pool_free(ctx, s->slab);
     pool_free(ctx, s->slab_i8);
+    pool_free(ctx, s->acc_i8);
     pool_free(ctx, s->partials);
     pool_free(ctx, s->u2_partials);
     pool_free(ctx, s->purity);

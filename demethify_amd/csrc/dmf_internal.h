@@ -168,14 +168,19 @@ hipError_t launch_rowpass_v2(const double* V, const unsigned short* D16, int SD,
                              double* u, double* u_prev, SolverState* state, int64_t N, int S, int n_c, int n_u,
                              int n_iter2, int mode, double* slab, double* u2_partials, int* grid_out, hipStream_t st);
 bool gram_i8_supported(int n_c, int n_u, int ND, int64_t N, int SD);
-int64_t gram_i8_slab_ints(int64_t N, int SD, int n_c, int n_u, int ND);
-// exact cross / uu Gram entries: features p = (feat_a[p], feat_b[p]) over x = (Rt, u), i32 slab [ny][weights][slots][SD]
-hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, int ND, const double* Rt, const double* u,
-                          int64_t N, int n_c, int n_u, const short* feat_a, const short* feat_b, int NF, int* slab,
+int64_t gram_i8_slab_words(int64_t N, int SD, int n_c, int n_u);  // i64 words of the slab
+int64_t gram_i8_acc_words(int S, int n_c, int n_u);               // i64 words of the reduction scratch (zero-initialised)
+// exact cross / uu Gram entries: features p = (feat_a[p], feat_b[p]) over x = (Rt, u), i64 slab [ny][2][slots][SD];
+// Rtp = the padded R_trunc copy (rows of 4 ceil(n_c / 4) doubles); Rtp, u, Dt8 16-byte aligned, u allocated to a
+// multiple of 16 bytes
+hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, int ND, const double* Rtp, const double* u,
+                          int64_t N, int n_c, int n_u, const short* feat_a, const short* feat_b, int NF, long long* slab,
                           const int* done_flag, int* ny_out, hipStream_t st);
-// gb rows of the u-dependent jobs from the i32 slab (jobs < NF) and the row pass's b_u slabs (jobs NF .. NF + n_u)
-hipError_t launch_gram_v2_reduce(const int* slab_i8, int ny, int ND, int NF, int SD, const double* slab_bu, int n_bu_slabs,
-                                 int n_u, int S, const int* dst_row, double* gb, const int* done_flag, hipStream_t st);
+// gb rows of the u-dependent jobs from the i64 slab (jobs < NF) and the row pass's b_u slabs (jobs NF .. NF + n_u);
+// acc_words: gram_i8_acc_words() i64 words, all zero before the first call (the kernels leave them zero again)
+hipError_t launch_gram_v2_reduce(const long long* slab_i8, int ny, int NF, int SD, const double* slab_bu, int n_bu_slabs,
+                                 int n_u, int S, long long* acc_words, const int* dst_row, double* gb, const int* done_flag,
+                                 hipStream_t st);
 
 // two percentiles over axis 0 of x[n][m] -> out0[m], out1[m] (out1 may be null); dmf_kernels_percentile.hip
 hipError_t launch_percentile_pair(const double* x, int64_t n, int64_t m, PercentilePlan p0, PercentilePlan p1,

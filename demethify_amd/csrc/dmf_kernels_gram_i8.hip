@@ -5,17 +5,17 @@
 // count:   cross[k][j][s] = sum_i (Rt_ik u_ij) d_is      uu[j<=l][s] = sum_i (u_ij u_il) d_is
 // i.e. one GEMM  G[p][s] = sum_i Z[i][p] D[i][s]  with Z (N x NF) formed on the fly and D the counts.  D is an
 // exact small integer and Z lies in [0, 1], so the GEMM is evaluated WITHOUT rounding: Z is written in fixed point,
-// z ~ rint(z 2^54) = sum_t a_t 256^t with seven balanced 8-bit digits a_t in [-128, 127], the counts likewise as
+// z ~ rint(z 2^52) = sum_t a_t 256^t with seven balanced 8-bit digits a_t in [-128, 127], the counts likewise as
 // one (d <= 127) or two (d <= 32639) balanced digits, every digit product is accumulated exactly in i32 by
-// v_mfma_i32_32x32x32_i8, the per-workgroup i32 sums are added as i64 and the digit weights are applied once at
-// the end (k_gram_v2_reduce).  The only rounding against exact arithmetic is rint(z 2^54): |error| <= 2^-55 per
-// feature value, zero for z >= 1/4 -- tighter than ANY f64 accumulation of the same sum, whose every addition
-// rounds at 2^-53 relative.  (FP64 needs one FMA per (row, feature, sample); here the same product costs 7 i8 MACs
-// at 64x the FP64 rate.)
+// v_mfma_i32_32x32x32_i8 and the per-workgroup sums are combined in 64-bit integer arithmetic (k_gram_v2_reduce /
+// k_gram_v2_finish): one conversion to f64 at the very end.  The only rounding against exact arithmetic is rint(z 2^52) of the exact product
+// z = Rt_ik u_ij: |error| <= 2^-53 per feature value, an ulp of 1.0 -- far below a single rounding of an f64
+// accumulation of the same sum (2^-53 RELATIVE to a running sum of ~N d z / 2).  (FP64 needs one FMA per
+// (row, feature, sample); here the same product costs 7 i8 MACs at 64x the FP64 rate.)
 //
 // Layouts.  B operand = counts as 8-bit digit planes Dt8[plane][row block of 32][sample block of 32][n 32][k 32]
 // (built once per problem, k_build_dt8): lane (n = l & 31, h = l >> 5) loads its 16 bytes k = 16 h .. 16 h + 15 with
-// one 16-B global load, the wave 1 KB contiguous.  A operand = digit t of feature p for the block's 32 rows, generated
+// one 16-B request, the wave 1 KB contiguous.  A operand = digit t of feature p for the block's 32 rows, generated
 // by the workgroup into LDS as Atile[h][m][16 B] (m = t * 32 NFT + p): conflict-free ds_read_b128 per (m, h).
 // Any bijection (h, byte) -> k the hardware applies is the same for A and B, so only "16 bytes per lane = 16
 // consecutive rows" matters; the C layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) is the
@@ -31,8 +31,8 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 namespace {
-constexpr int kNSL = 7;       // balanced base-256 digits of rint(z 2^54)
-constexpr int kXStride = 21;  // doubles per staged row of x = (Rt, u): K <= 20, odd stride against bank conflicts
+constexpr int kNSL = 7;       // balanced base-256 digits of rint(z 2^52)
+constexpr int kRing = 8;      // LDS-DMA ring: block slots
 constexpr int kMaxFeat = 96;
 }  // namespace
 
@@ -106,49 +106,81 @@ hipError_t launch_build_counts_int(const double* D, int64_t N, int S, int ND, un
 }
 
 // ------------------------------------------------------------------------------------------------ the GEMM
-// z -> the 64-bit integer rint(z 2^54) + bias, bias = 0x0000808080808080: bytes 0..5 of the sum, XOR 0x80, are the
-// balanced digits a_0..a_5, byte 6 is a_6 (0 <= a_6 <= 65: z <= 1)
-__device__ __forceinline__ void z_to_biased(double z, unsigned int& lo, unsigned int& hi) {
-    const double t = rint(z * 0x1p54);
-    const unsigned int h = (unsigned int)(t * 0x1p-32);             // trunc: t >= 0
-    const unsigned int l = (unsigned int)fma(-0x1p32, (double)h, t);  // exact remainder
+// Feature value z = xa * xb in [0, 1] -> the 64-bit integer rint(z 2^52) + bias: y = fma(xa, xb, 1.0) lies in [1, 2],
+// so its bit pattern minus that of 1.0 IS rint(xa xb 2^52) (one rounding, of the exact product, by the FMA itself).
+// bias = 0x0000808080808080: bytes 0..5 of the sum, XOR 0x80, are the balanced digits a_0..a_5, byte 6 is a_6
+// (0 <= a_6 <= 17).
+__device__ __forceinline__ void z_to_biased(double xa, double xb, unsigned int& lo, unsigned int& hi) {
+    const double y = fma(xa, xb, 1.0);
+    const unsigned int l = (unsigned int)__double2loint(y);
     const unsigned int l2 = l + 0x80808080u;
     lo = l2;
-    hi = h + 0x00008080u + (l2 < l ? 1u : 0u);
+    hi = (unsigned int)__double2hiint(y) - 0x3FF00000u + 0x00008080u + (l2 < l ? 1u : 0u);
 }
 
-template <int NFT, int ND>
+// 4 x 4 byte transpose: digits t = 0..3 of four 32-bit words w[0..3] (byte t of word r -> byte r of out[t])
+__device__ __forceinline__ void transpose4(const unsigned int (&w)[4], unsigned int (&out)[4]) {
+    const unsigned int a01 = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), b01 = __builtin_amdgcn_perm(w[1], w[0], 0x07030602u);
+    const unsigned int a23 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u), b23 = __builtin_amdgcn_perm(w[3], w[2], 0x07030602u);
+    out[0] = __builtin_amdgcn_perm(a23, a01, 0x05040100u);
+    out[1] = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+    out[2] = __builtin_amdgcn_perm(b23, b01, 0x05040100u);
+    out[3] = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
+}
+
+typedef __attribute__((address_space(1))) const void gmem_void;
+typedef __attribute__((address_space(3))) int lds_int;
+
+// Per 32-row block the workgroup needs 1 KB of count digits per wave and plane (B operand) and the block's rows of
+// R_trunc and u (32 K doubles).  Both arrive by LDS-DMA (global_load_lds_dwordx4: no VGPR destination, requests stay
+// in flight across barriers) into a ring of kRing block slots, kRing - 1 blocks ahead of their use: a block takes
+// ~0.3 us, an HBM miss under load several times that, and with ~500 accumulator / operand registers per wave there is
+// one wave per SIMD and no register room to stage that many loads.  Every wave issues the same number of DMA
+// instructions per block (ND + XL), so "block b + 1 has landed" is the counted wait vmcnt((kRing - 2)(ND + XL)) followed
+// by the workgroup barrier (the compiler does not order LDS reads behind LDS-DMA: the wait + barrier pair does).
+template <int NFT, int ND, int XL>
 __global__ __launch_bounds__(256) void k_gram_i8(const signed char* __restrict__ Dt8, int64_t plane_stride, int SB,
-                                                 const double* __restrict__ Rt, const double* __restrict__ u, int64_t N,
-                                                 int n_c, int n_u, const short* __restrict__ feat_a,
+                                                 const double* __restrict__ Rtp, int nct, const double* __restrict__ u,
+                                                 int64_t N, int n_c, int n_u, const short* __restrict__ feat_a,
                                                  const short* __restrict__ feat_b, int NF, int p0, int MFtot,
-                                                 int64_t rows_per_wg, int* __restrict__ slab, int SDs,
+                                                 int64_t rows_per_wg, long long* __restrict__ slab, int SDs,
                                                  const int* __restrict__ done_flag) {
     // features [p0, p0 + NF) of the table, NF <= 32 NFT: one launch per chunk of features (accumulator registers);
     // MFtot = feature slots of the whole slab
     constexpr int NWT = kNSL + ND - 1;   // digit weights 256^0 .. 256^(NWT-1)
-    constexpr int MF = 32 * NFT;         // feature slots per digit
+    constexpr int MF = 32 * NFT;         // feature slots per digit (<= 64: lane = feature)
     constexpr int MA = kNSL * MF;        // rows of the A tile
-    __shared__ __attribute__((aligned(16))) unsigned int atile[2][2 * MA * 4];  // [buf][h][m][4 dwords]
-    __shared__ double xs[2][32 * kXStride];
-    __shared__ short fa_s[kMaxFeat], fb_s[kMaxFeat];
+    constexpr int kSlotB = 4 * ND * 1024, kSlotX = XL * 4096, kSlot = kSlotB + kSlotX;
+    constexpr int kDmaPerBlock = ND + XL;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    char* __restrict__ ring = lds_raw;                                                            // [kRing][kSlot]
+    unsigned int* __restrict__ atile = reinterpret_cast<unsigned int*>(lds_raw + kRing * kSlot);  // [2][2 (h)][MA][4]
     if (done_flag != nullptr && *done_flag) return;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int K = n_c + n_u;
     const int sb = blockIdx.x * 4 + wave;  // this wave's block of 32 samples
     const bool wave_on = sb < SB;
-    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_wg;
+    const int sbc = wave_on ? sb : SB - 1;
+    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_wg;  // multiple of 32
     int64_t r_end = r_begin + rows_per_wg;
     if (r_end > N) r_end = N;
     const int nb = r_end > r_begin ? (int)((r_end - r_begin + 31) / 32) : 0;
+    if (nb == 0) return;
 
-    for (int i = tid; i < 2 * 2 * MA * 4; i += 256) (&atile[0][0])[i] = 0u;  // feature slots >= NF stay zero digits
-    for (int i = tid; i < NF; i += 256) {
-        fa_s[i] = feat_a[p0 + i];
-        fb_s[i] = feat_b[p0 + i];
+    for (int i = tid; i < 2 * 2 * MA * 4; i += 256) atile[i] = 0u;  // feature slots >= NF stay zero digits
+
+    // this lane's feature (lane = p): byte offsets of its two factors inside a block's x image
+    // [R_trunc rows: 32 x nct doubles (the padded copy: rows of 4 ceil(n_c / 4))][u rows: 32 x n_u doubles]
+    const bool feat_on = lane < NF;
+    int offA = 0, strideA = 0, offB = 0, strideB = 0;
+    if (feat_on) {
+        const int ia = feat_a[p0 + lane], ib = feat_b[p0 + lane];
+        offA = ia < n_c ? ia * 8 : 256 * nct + (ia - n_c) * 8;
+        strideA = ia < n_c ? nct * 8 : n_u * 8;
+        offB = ib < n_c ? ib * 8 : 256 * nct + (ib - n_c) * 8;
+        strideB = ib < n_c ? nct * 8 : n_u * 8;
     }
 
     v16i acc[NWT * NFT];
@@ -157,174 +189,211 @@ __global__ __launch_bounds__(256) void k_gram_i8(const signed char* __restrict__
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][e] = 0;
 
-    // x rows of a block: 32 x K doubles, element e = row * K + col -> thread e, e + 256, e + 512 (K <= 20: < 768)
-    int xrow[3], xcol[3];
+    const int n_chunk_rt = 16 * nct, n_chunks = 16 * (nct + n_u);  // 16-B pieces of a block's x image
+    // last 16-B piece of each array: rows of the padded R_trunc copy are multiples of 32 B; u may end on an odd
+    // double, its allocation is rounded up to 16 B by the solver (dmf_api.hip)
+    const int64_t rt_last = nct > 0 ? N * nct * 8 - 16 : 0;
+    const int64_t u_last = (N * n_u * 8 - 8) & ~(int64_t)15;
+    const int b_lane_off = (lane & 31) * 32 + (lane >> 5) * 16;  // Dt8 tile [n][k]: this lane's 16 bytes (n = l & 31, h = l >> 5)
+    const int64_t rb0 = r_begin >> 5;
+
+    auto issue = [&](int j) {
+        const int jc = j < nb ? j : nb - 1;  // beyond the range: a repeat of the last block keeps the DMA count uniform
+        char* __restrict__ slot = ring + (j % kRing) * kSlot;
+        const signed char* __restrict__ src = Dt8 + ((rb0 + jc) * SB + sbc) * 1024 + b_lane_off;
 #pragma unroll
-    for (int x = 0; x < 3; ++x) {
-        const int e = tid + 256 * x;
-        xrow[x] = e < 32 * K ? e / K : -1;
-        xcol[x] = e < 32 * K ? e - xrow[x] * K : 0;
-    }
-    auto load_x = [&](int b, double (&xr)[3]) {
-        const int64_t row0 = r_begin + (int64_t)b * 32;
+        for (int d = 0; d < ND; ++d)
+            __builtin_amdgcn_global_load_lds((gmem_void*)(src + d * plane_stride), (lds_int*)(slot + (wave * ND + d) * 1024), 16, 0, 0);
+        const int64_t row0 = r_begin + (int64_t)jc * 32;
 #pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            double val = 0.0;
-            if (xrow[x] >= 0 && row0 + xrow[x] < r_end)
-                val = xcol[x] < n_c ? Rt[(row0 + xrow[x]) * n_c + xcol[x]] : u[(row0 + xrow[x]) * n_u + (xcol[x] - n_c)];
-            xr[x] = val;
-        }
-    };
-    auto store_x = [&](int buf, const double (&xr)[3]) {
-#pragma unroll
-        for (int x = 0; x < 3; ++x)
-            if (xrow[x] >= 0) xs[buf][xrow[x] * kXStride + xcol[x]] = xr[x];
-    };
-    // digits of the block's features: task = (kq = 4 rows, p = feature); 4 x 4 byte transposes turn the rows'
-    // 64-bit fixed-point values into one dword (4 rows) per digit
-    auto generate = [&](int buf, int xbuf) {
-        unsigned int* __restrict__ at = atile[buf];
-        const double* __restrict__ xb = xs[xbuf];
-        const int kq = tid & 7;
-        for (int p = tid >> 3; p < NF; p += 32) {
-            const int ia = fa_s[p], ib = fb_s[p];
-            unsigned int lo[4], hi[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double* __restrict__ xrow = xb + (4 * kq + r) * kXStride;
-                z_to_biased(xrow[ia] * xrow[ib], lo[r], hi[r]);
+        for (int x = 0; x < XL; ++x) {
+            int c = tid + 256 * x;
+            if (c >= n_chunks) c = n_chunks - 1;  // lands in the slot's padding
+            const char* g;
+            if (c < n_chunk_rt) {
+                int64_t off = row0 * nct * 8 + (int64_t)c * 16;
+                g = reinterpret_cast<const char*>(Rtp) + (off < rt_last ? off : rt_last);
+            } else {
+                int64_t off = row0 * n_u * 8 + (int64_t)(c - n_chunk_rt) * 16;
+                g = reinterpret_cast<const char*>(u) + (off < u_last ? off : u_last);
             }
-            const unsigned int l01a = __builtin_amdgcn_perm(lo[1], lo[0], 0x05010400u), l01b = __builtin_amdgcn_perm(lo[1], lo[0], 0x07030602u);
-            const unsigned int l23a = __builtin_amdgcn_perm(lo[3], lo[2], 0x05010400u), l23b = __builtin_amdgcn_perm(lo[3], lo[2], 0x07030602u);
-            const unsigned int h01a = __builtin_amdgcn_perm(hi[1], hi[0], 0x05010400u), h01b = __builtin_amdgcn_perm(hi[1], hi[0], 0x07030602u);
-            const unsigned int h23a = __builtin_amdgcn_perm(hi[3], hi[2], 0x05010400u), h23b = __builtin_amdgcn_perm(hi[3], hi[2], 0x07030602u);
-            unsigned int dg[kNSL];
-            dg[0] = __builtin_amdgcn_perm(l23a, l01a, 0x05040100u) ^ 0x80808080u;
-            dg[1] = __builtin_amdgcn_perm(l23a, l01a, 0x07060302u) ^ 0x80808080u;
-            dg[2] = __builtin_amdgcn_perm(l23b, l01b, 0x05040100u) ^ 0x80808080u;
-            dg[3] = __builtin_amdgcn_perm(l23b, l01b, 0x07060302u) ^ 0x80808080u;
-            dg[4] = __builtin_amdgcn_perm(h23a, h01a, 0x05040100u) ^ 0x80808080u;
-            dg[5] = __builtin_amdgcn_perm(h23a, h01a, 0x07060302u) ^ 0x80808080u;
-            dg[6] = __builtin_amdgcn_perm(h23b, h01b, 0x05040100u);
-            const int h = kq >> 2, dw = kq & 3;
-#pragma unroll
-            for (int t = 0; t < kNSL; ++t) at[((h * MA + t * MF + p) << 2) + dw] = dg[t];
+            __builtin_amdgcn_global_load_lds((gmem_void*)g, (lds_int*)(slot + kSlotB + (x * 4 + wave) * 1024), 16, 0, 0);
         }
     };
-    auto load_b = [&](int b, v4i (&bq)[ND]) {
-        const int64_t rb = (r_begin >> 5) + b;  // r_begin is a multiple of 32
-        const signed char* __restrict__ src = Dt8 + (rb * SB + (wave_on ? sb : 0)) * 1024 + (lane & 31) * 32 + (lane >> 5) * 16;
+    // digits of block j's features into A tile `buf`: wave w = rows 8 w .. 8 w + 7, lane = feature
+    auto generate = [&](int buf, int j) {
+        const char* __restrict__ xb = ring + (j % kRing) * kSlot + kSlotB;
+        unsigned int lo[8], hi[8];
 #pragma unroll
-        for (int d = 0; d < ND; ++d) bq[d] = *reinterpret_cast<const v4i*>(src + d * plane_stride);
+        for (int r = 0; r < 8; ++r) {
+            const int row = 8 * wave + r;
+            const double xa0 = *reinterpret_cast<const double*>(xb + offA + row * strideA);  // (offset 0 without a feature)
+            const double xa = feat_on ? xa0 : 0.0;
+            const double xv = *reinterpret_cast<const double*>(xb + offB + row * strideB);
+            z_to_biased(xa, xv, lo[r], hi[r]);
+        }
+        unsigned int dg[2][8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const unsigned int l4[4] = {lo[4 * half], lo[4 * half + 1], lo[4 * half + 2], lo[4 * half + 3]};
+            const unsigned int h4[4] = {hi[4 * half], hi[4 * half + 1], hi[4 * half + 2], hi[4 * half + 3]};
+            unsigned int tl[4], th[4];
+            transpose4(l4, tl);
+            transpose4(h4, th);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dg[half][t] = tl[t] ^ 0x80808080u;
+            dg[half][4] = th[0] ^ 0x80808080u;
+            dg[half][5] = th[1] ^ 0x80808080u;
+            dg[half][6] = th[2];
+        }
+        unsigned int* __restrict__ at = atile + buf * (2 * MA * 4) + (((wave >> 1) * MA + lane) << 2) + (wave & 1) * 2;
+        if (MF == 64 || lane < MF) {  // (lane = feature slot; with 32 slots the upper half-wave has none)
+#pragma unroll
+            for (int t = 0; t < kNSL; ++t) {
+                typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<v2u*>(at + ((t * MF) << 2)) = v2u{dg[0][t], dg[1][t]};
+            }
+        }
     };
 
-    double xr[3];
-    v4i bcur[ND], bnext[ND];
-    __syncthreads();  // zeroed tiles, feature table
-    if (nb > 0) {
-        load_x(0, xr);
-        store_x(0, xr);
-        load_b(0, bcur);
-        __syncthreads();
-        generate(0, 0);
-        if (nb > 1) {
-            load_x(1, xr);
-            store_x(1, xr);
-        }
-        __syncthreads();
-    }
+    // ---- prologue: kRing - 1 blocks in flight, block 0's digits generated
+#pragma unroll 1
+    for (int j = 0; j < kRing - 1; ++j) issue(j);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    generate(0, 0);
+
+#pragma unroll 1
     for (int b = 0; b < nb; ++b) {
-        const int cur = b & 1, nxt = cur ^ 1;
-        if (b + 1 < nb) load_b(b + 1, bnext);
-        if (b + 2 < nb) load_x(b + 2, xr);
-        if (wave_on) {
-            const unsigned int* __restrict__ at = atile[cur] + (((lane >> 5) * MA + (lane & 31)) << 2);
+        const int cur = b & 1;
+        issue(b + kRing - 1);  // into the slot of block b - 1, consumed before the previous barrier
+        // own DMA of blocks <= b + 1 landed, own LDS writes (A[cur]) done; then everyone's
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kRing - 2) * kDmaPerBlock) : "memory");
+        __builtin_amdgcn_s_barrier();
+        // (no branches in here: a wave beyond the last sample block multiplies a repeat tile into accumulators that
+        // are never stored, lanes without a feature produce the all-zero digits of z = 0 -- so that the scheduler may
+        // place the digit arithmetic of block b + 1 under the matrix-core time of block b)
+        const char* __restrict__ bs = ring + (b % kRing) * kSlot + wave * ND * 1024 + lane * 16;
+        v4i bq[ND];
 #pragma unroll
-            for (int t = 0; t < kNSL; ++t)
+        for (int d = 0; d < ND; ++d) bq[d] = *reinterpret_cast<const v4i*>(bs + d * 1024);
+        const unsigned int* __restrict__ at = atile + cur * (2 * MA * 4) + (((lane >> 5) * MA + (lane & 31)) << 2);
+        v4i aop[kNSL * NFT];  // every A operand of the block up front: one LDS round trip, not one per MFMA
 #pragma unroll
-                for (int f = 0; f < NFT; ++f) {
-                    const v4i a = *reinterpret_cast<const v4i*>(at + ((t * MF + 32 * f) << 2));
+        for (int t = 0; t < kNSL; ++t)
 #pragma unroll
-                    for (int d = 0; d < ND; ++d)
-                        acc[(t + d) * NFT + f] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bcur[d], acc[(t + d) * NFT + f], 0, 0, 0);
-                }
-        }
-        if (b + 1 < nb) generate(nxt, nxt);  // xs[nxt] holds block b + 1
-        if (b + 2 < nb) store_x(cur, xr);    // xs[cur] (block b) was consumed when A[cur] was generated
-        __syncthreads();
+            for (int f = 0; f < NFT; ++f) aop[t * NFT + f] = *reinterpret_cast<const v4i*>(at + ((t * MF + 32 * f) << 2));
+        generate(cur ^ 1, b + 1 < nb ? b + 1 : b);
 #pragma unroll
-        for (int d = 0; d < ND; ++d) bcur[d] = bnext[d];
-    }
-
-    // ---- slab[y][weight][feature slot][sample] (i32): exact partial sums of this row range
-    if (wave_on) {
-        const int n = lane & 31, h = lane >> 5;
-        int* __restrict__ out = slab + ((int64_t)blockIdx.y * NWT * MFtot + p0) * SDs + sb * 32 + n;
-#pragma unroll
-        for (int wt = 0; wt < NWT; ++wt)
+        for (int t = 0; t < kNSL; ++t)
 #pragma unroll
             for (int f = 0; f < NFT; ++f)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const int p = 32 * f + m;
-                    if (p < NF) out[(int64_t)(wt * MFtot + p) * SDs] = acc[wt * NFT + f][e];
+                for (int d = 0; d < ND; ++d)
+                    acc[(t + d) * NFT + f] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[t * NFT + f], bq[d], acc[(t + d) * NFT + f], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (repeat) DMAs must not outlive the workgroup's LDS
+
+    // ---- slab[y][half][feature slot][sample] (i64): the exact partial sums of this row range with the digit weights
+    // applied inside each half, lo = sum_{w < 4} acc_w 256^w, hi = sum_{w >= 4} acc_w 256^(w - 4)  (|acc_w| < 2^31, so
+    // both fit 56 bits); the full sum is lo + 2^32 hi
+    if (wave_on) {
+        const int n = lane & 31, h = lane >> 5;
+        long long* __restrict__ out = slab + ((int64_t)blockIdx.y * 2 * MFtot + p0) * SDs + sb * 32 + n;
+#pragma unroll
+        for (int f = 0; f < NFT; ++f)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int p = 32 * f + m;
+                long long lo = 0, hi = 0;
+#pragma unroll
+                for (int wt = 0; wt < NWT; ++wt) {
+                    const long long v = (long long)acc[wt * NFT + f][e];
+                    if (wt < 4) lo += v << (8 * wt);
+                    else hi += v << (8 * (wt - 4));
                 }
+                if (p < NF) {
+                    out[(int64_t)p * SDs] = lo;
+                    out[(int64_t)(MFtot + p) * SDs] = hi;
+                }
+            }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ reduce
-// gb[dst_row[job]][s] for every u-dependent job of the solver's table:
-//   jobs < n_feat (cross / uu):  2^-54 sum_w 256^w (sum_y slab_i8[y][w][job][s])      (i64 sums, weights applied once)
-//   jobs >= n_feat (b_u[j]):     sum_g slab_bu[g][j][s] in workgroup order (fixed order: deterministic)
-__global__ __launch_bounds__(256) void k_gram_v2_reduce(const int* __restrict__ slab_i8, int ny, int NWT, int MF, int SDs,
+// Stage 1 (grid: sample blocks x jobs x kRedChunks): jobs < n_feat add their chunk of the i64 slabs into
+// acc64[half][job][S] with 64-bit integer atomics (exact, so the order of the adds cannot matter); jobs >= n_feat
+// (b_u[j]) sum their chunk of the row pass's f64 slabs in slab order into bu_part[chunk][j][S].
+// Stage 2 (k_gram_v2_finish): gb row of every u-dependent job; acc64 is zeroed again for the next outer iteration.
+constexpr int kRedChunks = 8;
+
+__global__ __launch_bounds__(256) void k_gram_v2_reduce(const long long* __restrict__ slab_i8, int ny, int MF, int SDs,
                                                         const double* __restrict__ slab_bu, int n_bu_slabs, int n_u,
-                                                        int n_feat, int S, const int* __restrict__ dst_row,
-                                                        double* __restrict__ gb, const int* __restrict__ done_flag) {
-    __shared__ long long part[3][8][64];
+                                                        int n_feat, int S, unsigned long long* __restrict__ acc64,
+                                                        double* __restrict__ bu_part, const int* __restrict__ done_flag) {
+    __shared__ long long part[3][2][64];
     __shared__ double partd[3][64];
     if (done_flag != nullptr && *done_flag) return;
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;  // 4 groups split the slabs
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int s = blockIdx.x * 64 + lane;
-    const int job = blockIdx.y;
+    const int job = blockIdx.y, chunk = blockIdx.z;
     const bool active = s < S;
     const int sc = active ? s : S - 1;
     if (job < n_feat) {
-        long long tw[8];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) tw[w] = 0;
-        for (int y = grp; y < ny; y += 4) {
-            const int* __restrict__ base = slab_i8 + ((int64_t)y * NWT * MF + job) * SDs + sc;
-#pragma unroll
-            for (int w = 0; w < 8; ++w)
-                if (w < NWT) tw[w] += base[(int64_t)w * MF * SDs];
+        const int per = (ny + kRedChunks - 1) / kRedChunks;
+        const int y0 = chunk * per, y1 = y0 + per < ny ? y0 + per : ny;
+        long long lo = 0, hi = 0;
+        for (int y = y0 + grp; y < y1; y += 4) {
+            const long long* __restrict__ base = slab_i8 + ((int64_t)y * 2 * MF + job) * SDs + sc;
+            lo += base[0];
+            hi += base[(int64_t)MF * SDs];
         }
         if (grp > 0) {
-#pragma unroll
-            for (int w = 0; w < 8; ++w) part[grp - 1][w][lane] = tw[w];
+            part[grp - 1][0][lane] = lo;
+            part[grp - 1][1][lane] = hi;
         }
         __syncthreads();
-        if (grp == 0 && active) {
-            double r = 0.0;
-#pragma unroll
-            for (int w = 7; w >= 0; --w) {
-                if (w < NWT) {
-                    const long long t = ((tw[w] + part[0][w][lane]) + part[1][w][lane]) + part[2][w][lane];
-                    r = fma(r, 256.0, (double)t);  // Horner from the heaviest digit: <= 1 rounding per step
-                }
-            }
-            gb[(int64_t)dst_row[job] * S + s] = r * 0x1p-54;
+        if (grp == 0 && active && y0 < y1) {
+            lo += part[0][0][lane] + part[1][0][lane] + part[2][0][lane];
+            hi += part[0][1][lane] + part[1][1][lane] + part[2][1][lane];
+            atomicAdd(acc64 + (int64_t)job * S + s, (unsigned long long)lo);
+            atomicAdd(acc64 + ((int64_t)n_feat + job) * S + s, (unsigned long long)hi);
         }
     } else {
         const int j = job - n_feat;
+        const int per = (n_bu_slabs + kRedChunks - 1) / kRedChunks;  // slabs of this chunk, split over the 4 waves
+        const int c0 = chunk * per, c1 = c0 + per < n_bu_slabs ? c0 + per : n_bu_slabs;
+        const int perw = (per + 3) / 4;
+        const int g0 = c0 + grp * perw, g1 = g0 + perw < c1 ? g0 + perw : c1;
         double acc = 0.0;
-        // fixed partition and order of the partial sums: bitwise reproducible
-        const int per = (n_bu_slabs + 3) / 4;
-        const int g0 = grp * per, g1 = g0 + per < n_bu_slabs ? g0 + per : n_bu_slabs;
-        for (int g = g0; g < g1; ++g) acc += slab_bu[((int64_t)g * n_u + j) * S + sc];
+        for (int g = g0; g < g1; ++g) acc += slab_bu[((int64_t)g * n_u + j) * S + sc];  // slab order: reproducible
         if (grp > 0) partd[grp - 1][lane] = acc;
         __syncthreads();
-        if (grp == 0 && active) gb[(int64_t)dst_row[job] * S + s] = ((acc + partd[0][lane]) + partd[1][lane]) + partd[2][lane];
+        if (grp == 0 && active) bu_part[((int64_t)chunk * n_u + j) * S + s] = ((acc + partd[0][lane]) + partd[1][lane]) + partd[2][lane];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_gram_v2_finish(unsigned long long* __restrict__ acc64, const double* __restrict__ bu_part,
+                                                       int n_u, int n_feat, int S, const int* __restrict__ dst_row,
+                                                       double* __restrict__ gb, const int* __restrict__ done_flag) {
+    if (done_flag != nullptr && *done_flag) return;
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    const int job = blockIdx.y;
+    if (s >= S) return;
+    if (job < n_feat) {
+        unsigned long long* plo = acc64 + (int64_t)job * S + s;
+        unsigned long long* phi = acc64 + ((int64_t)n_feat + job) * S + s;
+        const long long lo = (long long)*plo, hi = (long long)*phi;
+        *plo = 0ull;  // ready for the next outer iteration
+        *phi = 0ull;
+        // sum = lo + 2^32 hi (an integer of up to ~95 bits) -> f64: the conversions and the FMA round at 2^-53 relative
+        gb[(int64_t)dst_row[job] * S + s] = fma((double)hi, 0x1p32, (double)lo) * 0x1p-52;
+    } else {
+        const int j = job - n_feat;
+        double acc = 0.0;
+        for (int c = 0; c < kRedChunks; ++c) acc += bu_part[((int64_t)c * n_u + j) * S + s];
+        gb[(int64_t)dst_row[job] * S + s] = acc;
     }
 }
 
@@ -340,8 +409,6 @@ void gram_i8_geometry(int64_t N, int SD, int* nsh, int* ny, int64_t* rows_per_wg
     *ny = (int)((N + rpw - 1) / rpw);
 }
 
-int gram_i8_weights(int ND) { return kNSL + ND - 1; }
-
 bool gram_i8_supported(int n_c, int n_u, int ND, int64_t N, int SD) {
     const int nf = n_c * n_u + n_u * (n_u + 1) / 2;
     if (n_c + n_u > 20 || nf < 1 || nf > kMaxFeat || ND < 1 || ND > 2) return false;
@@ -351,28 +418,47 @@ bool gram_i8_supported(int n_c, int n_u, int ND, int64_t N, int SD) {
     return rpw * 128 * 128 * ND < (int64_t)1 << 31;  // i32 accumulators cannot overflow within a row range
 }
 
-int64_t gram_i8_slab_ints(int64_t N, int SD, int n_c, int n_u, int ND) {
+// i64 words: [ny][2][slots][SD] slab + acc64[2][nf][S] + (as doubles) bu_part[kRedChunks][n_u][S]
+int64_t gram_i8_slab_words(int64_t N, int SD, int n_c, int n_u) {
     const int nf = n_c * n_u + n_u * (n_u + 1) / 2;
     int nsh, ny;
     int64_t rpw;
     gram_i8_geometry(N, SD, &nsh, &ny, &rpw);
-    return (int64_t)ny * gram_i8_weights(ND) * ((nf + 31) / 32 * 32) * SD;
+    return (int64_t)ny * 2 * ((nf + 31) / 32 * 32) * SD;
+}
+int64_t gram_i8_acc_words(int S, int n_c, int n_u) {
+    const int nf = n_c * n_u + n_u * (n_u + 1) / 2;
+    return (int64_t)2 * nf * S + (int64_t)kRedChunks * n_u * S;
 }
 
-template <int NFT, int ND>
-static hipError_t launch_gram_i8_t(const signed char* Dt8, int64_t plane_stride, int SD, const double* Rt, const double* u,
+size_t gram_i8_lds_bytes(int nft, int nd, int xl) {
+    return (size_t)kRing * (4 * nd * 1024 + xl * 4096) + (size_t)2 * 2 * (kNSL * 32 * nft) * 16;
+}
+
+template <int NFT, int ND, int XL>
+static hipError_t launch_gram_i8_t(const signed char* Dt8, int64_t plane_stride, int SD, const double* Rtp, const double* u,
                                    int64_t N, int n_c, int n_u, const short* fa, const short* fb, int NF, int p0, int MFtot,
-                                   int* slab, const int* done_flag, hipStream_t st) {
+                                   long long* slab, const int* done_flag, hipStream_t st) {
     int nsh, ny;
     int64_t rpw;
     gram_i8_geometry(N, SD, &nsh, &ny, &rpw);
-    hipLaunchKernelGGL((k_gram_i8<NFT, ND>), dim3(nsh, ny), dim3(256), 0, st, Dt8, plane_stride, SD / 32, Rt, u, N, n_c,
-                       n_u, fa, fb, NF, p0, MFtot, rpw, slab, SD, done_flag);
+    const size_t lds = gram_i8_lds_bytes(NFT, ND, XL);
+    static bool lds_limit_raised[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (lds > 48 * 1024 && !lds_limit_raised[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gram_i8<NFT, ND, XL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return e;
+        lds_limit_raised[dev] = true;
+    }
+    hipLaunchKernelGGL((k_gram_i8<NFT, ND, XL>), dim3(nsh, ny), dim3(256), lds, st, Dt8, plane_stride, SD / 32, Rtp,
+                       (n_c + 3) / 4 * 4, u, N, n_c, n_u, fa, fb, NF, p0, MFtot, rpw, slab, SD, done_flag);
     return hipGetLastError();
 }
 
-hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, int ND, const double* Rt, const double* u,
-                          int64_t N, int n_c, int n_u, const short* fa, const short* fb, int NF, int* slab,
+hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, int ND, const double* Rtp, const double* u,
+                          int64_t N, int n_c, int n_u, const short* fa, const short* fb, int NF, long long* slab,
                           const int* done_flag, int* ny_out, hipStream_t st) {
     int nsh, ny;
     int64_t rpw;
@@ -385,19 +471,28 @@ hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, 
     for (int p0 = 0; p0 < NF; p0 += chunk) {
         const int nf = NF - p0 < chunk ? NF - p0 : chunk;
         hipError_t e;
-        if (ND == 1 && nf > 32) e = launch_gram_i8_t<2, 1>(Dt8, plane_stride, SD, Rt, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
-        else if (ND == 1) e = launch_gram_i8_t<1, 1>(Dt8, plane_stride, SD, Rt, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
-        else e = launch_gram_i8_t<1, 2>(Dt8, plane_stride, SD, Rt, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
+#define DMF_GI8(F, D_, X)                                                                                                 \
+    e = launch_gram_i8_t<F, D_, X>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st)
+        const bool wide = (n_c + 3) / 4 * 4 + n_u > 16;  // x image of a block beyond 4 KB: two DMA pieces per thread
+        if (ND == 1 && nf > 32) { if (wide) DMF_GI8(2, 1, 2); else DMF_GI8(2, 1, 1); }
+        else if (ND == 1) { if (wide) DMF_GI8(1, 1, 2); else DMF_GI8(1, 1, 1); }
+        else { if (wide) DMF_GI8(1, 2, 2); else DMF_GI8(1, 2, 1); }
+#undef DMF_GI8
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 
-hipError_t launch_gram_v2_reduce(const int* slab_i8, int ny, int ND, int NF, int SD, const double* slab_bu, int n_bu_slabs,
-                                 int n_u, int S, const int* dst_row, double* gb, const int* done_flag, hipStream_t st) {
+hipError_t launch_gram_v2_reduce(const long long* slab_i8, int ny, int NF, int SD, const double* slab_bu, int n_bu_slabs,
+                                 int n_u, int S, long long* acc_words, const int* dst_row, double* gb, const int* done_flag,
+                                 hipStream_t st) {
     const int MF = (NF + 31) / 32 * 32;
-    hipLaunchKernelGGL(k_gram_v2_reduce, dim3((S + 63) / 64, NF + n_u), dim3(256), 0, st, slab_i8, ny, gram_i8_weights(ND),
-                       MF, SD, slab_bu, n_bu_slabs, n_u, NF, S, dst_row, gb, done_flag);
+    unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(acc_words);
+    double* bu_part = reinterpret_cast<double*>(acc_words + (int64_t)2 * NF * S);
+    hipLaunchKernelGGL(k_gram_v2_reduce, dim3((S + 63) / 64, NF + n_u, kRedChunks), dim3(256), 0, st, slab_i8, ny, MF, SD,
+                       slab_bu, n_bu_slabs, n_u, NF, S, acc64, bu_part, done_flag);
+    hipLaunchKernelGGL(k_gram_v2_finish, dim3((S + 63) / 64, NF + n_u), dim3(64), 0, st, acc64, bu_part, n_u, NF, S, dst_row,
+                       gb, done_flag);
     return hipGetLastError();
 }
 
