@@ -38,7 +38,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6  # FP64 vector = FP64 matrix peak (256 CUs x 4 SIMDs x 16 FMA/clk x 2.4 GHz)
-T2 = 20                 # inner iterations (CLI default, demethify.py:64)
+T2 = int(os.environ.get("DMF_BENCH_T2", "20"))  # inner iterations (CLI default 20, demethify.py:64; env: experiments only)
 WORKLOADS = {
     # name: (N, S, n_c, n_u)
     "headline_1e6x256_12+4": (1_000_000, 256, 12, 4),

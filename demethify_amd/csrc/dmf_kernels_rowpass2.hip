@@ -19,7 +19,7 @@
 //   phase B (one wave, round robin) sums the partials and runs the n_iter2 accelerated projected-gradient steps,
 //           lane = (row, unknown); u / u_ go to HBM and u to LDS
 //   -- barrier Y --
-//   phase C lane = sample: bu[j] += (d v) u_j over the 16 rows, in registers across all blocks of the workgroup
+//   phase C b_u[j][s] += sum_rows u_j (d v) on the 4x4x4 FP64 MFMA, accumulators in registers across all blocks
 // Rows beyond N in the last block read a clamped V row and zero counts (D16 is zero-padded to a multiple of 16 rows
 // and of 64 columns), so they add nothing; their u is never stored.
 //
@@ -27,6 +27,7 @@
 #include "dmf_device.h"
 #include "dmf_internal.h"
 #include "dmf_phaseb.h"
+#include <cstdlib>
 
 namespace dmf {
 
@@ -35,6 +36,25 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
+// Diagnostic build only (tools/rowpass2_probe.hip defines DMF_STAMPS): per-wave cycle sums of the kernel's segments
+// go to a debug buffer of their own; the product build compiles none of it.
+#ifdef DMF_STAMPS
+#define DMF2_STAMP_DECL unsigned long long st_last = dmf2_stamp(), st_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DMF2_STAMP(i) { const unsigned long long st_now = dmf2_stamp(); st_seg[i] += st_now - st_last; st_last = st_now; }
+#define DMF2_STAMP_FLUSH if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) stamps_out[((size_t)blockIdx.x * 4 + wave) * 8 + i_] = st_seg[i_];
+__device__ __forceinline__ unsigned long long dmf2_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#else
+#define DMF2_STAMP_DECL
+#define DMF2_STAMP(i)
+#define DMF2_STAMP_FLUSH
+#endif
+
 namespace {
 constexpr int kRowV = 66;  // V tile row: 64 samples + 16 B pad (f64)
 constexpr int kRowD = 68;  // D tile row: 64 samples + 16 B pad (f32)
@@ -42,12 +62,46 @@ constexpr int kTileVBytes2 = 16 * kRowV * 8;
 constexpr int kTileBytes2 = kTileVBytes2 + 16 * kRowD * 4;  // one column group
 }  // namespace
 
+// One accelerated projected-gradient step of a row group (deconvolution.py:83-88): (cur, prev) = (u, u_) in,
+// prev = the new u out (cur is then u_).  AT_PREV: gradient at the previous iterate (deconvolution.py:163) instead
+// of the extrapolated point (:88).  c and M arrive pre-scaled by 1 / l_w (M negated).
+template <int NU, bool AT_PREV>
+__device__ __forceinline__ void inner_step(double cur, double& prev, double cj, const double (&Ms)[NU], int b_lo, int b_hi,
+                                           int t2, int lane0) {
+    const double beta = __hiloint2double(__builtin_amdgcn_readlane(b_hi, t2), __builtin_amdgcn_readlane(b_lo, t2));
+    const double ut = fma(beta, cur - prev, cur);
+    // Phase B runs alone on its SIMD's FP64 pipe most of the time and is then bound by the ~13 cycles each DEPENDENT
+    // instruction takes, so the products -M[j][l] x_l are formed independently and summed as a tree (depth 7 per step
+    // instead of 11 for one FMA chain)
+    prev = f_add_clamp01(ut + cj, f_dot_tree<NU, 0, NU>(AT_PREV ? cur : ut, Ms, lane0));
+}
+
+template <int NU, bool AT_PREV>
+__device__ __forceinline__ void inner_steps(double& uu, double& up, double cj, const double (&Ms)[NU], int b_lo, int b_hi,
+                                            int t_end, int lane0) {
+    int t2 = 0;
+    for (; t2 + 1 < t_end; t2 += 2) {
+        inner_step<NU, AT_PREV>(uu, up, cj, Ms, b_lo, b_hi, t2, lane0);      // new u in `up`, previous u in `uu`
+        inner_step<NU, AT_PREV>(up, uu, cj, Ms, b_lo, b_hi, t2 + 1, lane0);  // and back
+    }
+    if (t2 < t_end) {
+        inner_step<NU, AT_PREV>(uu, up, cj, Ms, b_lo, b_hi, t2, lane0);
+        const double tmp = uu;
+        uu = up;
+        up = tmp;
+    }
+}
+
 template <int NKC, int NU>
 __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
     const double* __restrict__ V, const unsigned short* __restrict__ D16, int SD, const double* __restrict__ Rtp,
     const double* __restrict__ alpha, double* __restrict__ u, double* __restrict__ u_prev,
     const SolverState* __restrict__ state, int64_t N, int S, int n_c, int n_iter2, int mode,
-    double* __restrict__ slab, double* __restrict__ u2_partials) {
+    double* __restrict__ slab, double* __restrict__ u2_partials
+#ifdef DMF_STAMPS
+    , unsigned long long* __restrict__ stamps_out
+#endif
+    ) {
     static_assert(NU >= 1 && NU <= 4, "one phase-B pass per block, 4x4x4 MFMA for the c product");
     constexpr int NCT = 4 * NKC;
     constexpr int NP = NU * (NU + 1) / 2;
@@ -126,8 +180,21 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
     v2d pv[8];
     v4u pd[2];
     double nrt[NKC > 0 ? NKC : 1];
+    double pu, pup;  // u / u_ of lane (row, unknown) for the wave that runs the block's inner iterations
+    constexpr int RPWB = 64 / NU;  // >= 16 rows per wave: one phase-B pass covers the block
+    const int rl = lane / NU, jb = lane - rl * NU;
+    const bool b_lane = rl < 16 && rl < RPWB;
     auto prefetch = [&](int64_t blk) {
         const int64_t r0 = blk * 16;
+        {
+            // FIRST in the batch: the tile store's wait for the (younger) tile loads then covers them, and phase B
+            // finds its u / u_ complete without a vmcnt wait of its own -- a wait there would also cover the NEXT
+            // block's prefetch, issued just before barrier X, and put a whole HBM round trip on the critical path.
+            // (unconditional on purpose: loads under a branch make the compiler's s_waitcnt placement pessimistic)
+            const int64_t gi = (b_lane && r0 + rl < N) ? (r0 + rl) * NU + jb : 0;
+            pu = u[gi];
+            pup = u_prev[gi];
+        }
         if (r0 + 16 <= N) {  // (wave-uniform)
             const double* __restrict__ rb = Rtp + r0 * NCT + m16 * NCT + q;
 #pragma unroll
@@ -151,18 +218,15 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
     };
     if (nk > 0) prefetch(blockIdx.x);
 
-    double bu[NU];
-#pragma unroll
-    for (int j = 0; j < NU; ++j) bu[j] = 0.0;
+    double bu[4] = {0.0, 0.0, 0.0, 0.0};  // b_u[unknown q][sample 16 t + m16] of this wave's column group, t = 0..3
     double u2_acc = 0.0;
-    // 64 / NU >= 16 rows per wave: one phase-B pass covers the block
-    const int rl = lane / NU, jb = lane - rl * NU;
-    const bool b_lane = rl < 16;
 
+    DMF2_STAMP_DECL
     for (int s = 0; s < nk; ++s) {
         const int64_t blk = blockIdx.x + (int64_t)s * gridDim.x;
         const int64_t row0 = blk * 16;
         // ---- tile store (waits for the prefetched loads)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             *reinterpret_cast<v2d*>(tileV + (2 * i + ld_row) * kRowV + ld_col) = pv[i];
@@ -176,14 +240,15 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
         double rtop[NKC > 0 ? NKC : 1];
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) rtop[kc] = nrt[kc];  // B operand of the first product: Rt^T[k = 4 kc + q][n = row]
-        // the wave that will run this block's inner iterations fetches its u / u_ now
+        // the block's u / u_ arrived with the tile (the next prefetch reuses pu / pup before phase B runs)
         const bool my_turn = wave == s % NW;
         const bool ok = b_lane && row0 + rl < N;
         const int64_t gi = ok ? (row0 + rl) * NU + jb : 0;
-        // (unconditional on purpose: loads under a branch make the compiler's s_waitcnt placement pessimistic)
-        const double uu0 = u[gi];
-        const double up0 = u_prev[gi];
+        const double uu0 = pu;
+        const double up0 = pup;
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_setprio(0);
+        DMF2_STAMP(0)  // tile store (vmcnt wait for the prefetch)
 
         // ---- phase A: strips of 16 samples; the LDS reads of strip t + 1 are issued before the MFMAs of strip t,
         // and the E chain of strip t + 1 is slotted between the c / M MFMAs of strip t (a dependent FP64 MFMA
@@ -233,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
         (void)run_strip(sb, e3, sb, a1r[3], a2r[3], ppr[3], false);
         macc += macc1;
         const double csm = csm0 + csm1;
+        DMF2_STAMP(1)  // phase A
         // the next block's global loads: their staging registers were free during phase A, and the loads have
         // phases B and C (and the other workgroups' turns on this CU) to land
         if (s + 1 < nk) prefetch(blk + gridDim.x);
@@ -245,7 +311,12 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
                 if (p < NP) mine[(NU + p) * 16 + m16] = macc[rr];
             }
         }
-        __syncthreads();  // ---- barrier X
+        DMF2_STAMP(2)  // prefetch issue + partials
+        // (a bare barrier behind an LDS-only wait: __syncthreads() would also drain vmcnt, i.e. stall every wave on
+        // the prefetch it has just issued)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ---- barrier X
+        DMF2_STAMP(3)  // wait X
 
         // ---- phase B: row-local inner iterations, lane = (row, unknown j); c and M pre-scaled by 1 / l_w
         if (my_turn) {
@@ -275,25 +346,10 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
                 const double bvec = beta_tab[tl];
                 const int b_lo = __double2loint(bvec), b_hi = __double2hiint(bvec);
                 const int t_end = n_iter2 - t0 < 64 ? n_iter2 - t0 : 64;
-                if (mode == 1) {  // deconvolution.py:163: gradient at the previous iterate
-#pragma unroll 2
-                    for (int t2 = 0; t2 < t_end; ++t2) {
-                        const double beta = __hiloint2double(__builtin_amdgcn_readlane(b_hi, t2),
-                                                             __builtin_amdgcn_readlane(b_lo, t2));
-                        const double ut = fma(beta, uu - up, uu);
-                        up = uu;
-                        uu = f_step_chain<NU>(ut + cj, up, Ms, lane0);
-                    }
-                } else {          // deconvolution.py:88: gradient at the extrapolated point
-#pragma unroll 2
-                    for (int t2 = 0; t2 < t_end; ++t2) {
-                        const double beta = __hiloint2double(__builtin_amdgcn_readlane(b_hi, t2),
-                                                             __builtin_amdgcn_readlane(b_lo, t2));
-                        const double ut = fma(beta, uu - up, uu);
-                        up = uu;
-                        uu = f_step_chain<NU>(ut + cj, ut, Ms, lane0);
-                    }
-                }
+                // (u, u_) swap roles every step: written out in pairs so that no register copies sit on the chain
+                // (the loop holds v_readlane, a convergent operation the unroller will not split by itself)
+                if (mode == 1) inner_steps<NU, true>(uu, up, cj, Ms, b_lo, b_hi, t_end, lane0);
+                else inner_steps<NU, false>(uu, up, cj, Ms, b_lo, b_hi, t_end, lane0);
             }
             if (b_lane) ubuf[rl * NU + jb] = ok ? uu : 0.0;  // rows beyond N: phase C multiplies them by zero counts
             if (ok) {
@@ -303,33 +359,51 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
             }
             __builtin_amdgcn_s_setprio(0);
         }
-        __syncthreads();  // ---- barrier Y
+        DMF2_STAMP(4)  // phase B (or nothing)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ---- barrier Y
+        DMF2_STAMP(5)  // wait Y
 
-        // ---- phase C: lane = sample of this wave's column group; bu[j] += (d v) u_j over the block's rows
+        // ---- phase C: b_u[j][s] += sum_rows u[row][j] (d v)[row][s] on the 4x4x4 (4 blocks) FP64 MFMA: block = sample
+        // quad of a 16-sample strip, i = unknown, j = sample in the quad, k = row in a quad of rows (A[b][i][k] sits
+        // at lane 16 k + 4 b + i, B[b][k][j] at lane 16 k + 4 b + j, the result D[b][i][j] at lane 16 i + 4 b + j:
+        // tools/mfma_probe.hip).  Lane (q, m16) therefore reads (d v) of row 4 R + q, sample 16 t + m16 and u of row
+        // 4 R + q, unknown m16 & 3; the 32 tile reads of the block are independent and go out in two batches (a lane =
+        // sample loop with per-row broadcast reads of u spent ~1.6k cycles per block on LDS round trips).
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const double t = (double)tileD[r * kRowD + lane] * tileV[r * kRowV + lane];
-            if constexpr ((NU & 1) == 0) {
+        for (int half = 0; half < 2; ++half) {
+            double vv[2][4], ua[2];
+            float dd[2][4];
 #pragma unroll
-                for (int j = 0; j < NU; j += 2) {  // 16-B broadcast reads
-                    const v2d two = *reinterpret_cast<const v2d*>(ubuf + r * NU + j);
-                    bu[j] = fma(t, two.x, bu[j]);
-                    bu[j + 1] = fma(t, two.y, bu[j + 1]);
+            for (int rr = 0; rr < 2; ++rr) {
+                const int row = 4 * (2 * half + rr) + q;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    vv[rr][t] = tileV[row * kRowV + 16 * t + m16];
+                    dd[rr][t] = tileD[row * kRowD + 16 * t + m16];
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < NU; ++j) bu[j] = fma(t, ubuf[r * NU + j], bu[j]);
+                ua[rr] = (m16 & 3) < NU ? ubuf[row * NU + (m16 & 3)] : 0.0;
             }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    bu[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ua[rr], (double)dd[rr][t] * vv[rr][t], bu[t], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
+        DMF2_STAMP(6)  // phase C
         // (the next iteration's tile store touches this wave's own tile only; ubuf and red are rewritten behind
         // the next barrier X / by phase A after this wave's own phase C)
     }
 
+    DMF2_STAMP_FLUSH
     // ---- b_u slab of this workgroup [NU][S] and its share of ||u||_F^2
-    const int sC = wcol0 + lane;
-    if (sC < S) {
+    if (q < NU) {
 #pragma unroll
-        for (int j = 0; j < NU; ++j) slab[((int64_t)blockIdx.x * NU + j) * S + sC] = bu[j];
+        for (int t = 0; t < 4; ++t) {
+            const int sC = wcol0 + 16 * t + m16;
+            if (sC < S) slab[((int64_t)blockIdx.x * NU + q) * S + sC] = bu[t];
+        }
     }
     const double w2 = wave_sum(u2_acc);
     if (lane == 0) u2red[wave] = w2;
@@ -355,7 +429,8 @@ bool rowpass_v2_supported(int S, int n_c, int n_u, int n_iter2) {
 
 int rowpass_v2_grid(int64_t N, int S) {
     const int NW = (S + 63) / 64;
-    const int per_cu = 8 / NW;  // two waves per SIMD: NW = 4 -> 2, 3 -> 2, 2 -> 4, 1 -> 8 workgroups per CU
+    int per_cu = 8 / NW;  // two waves per SIMD: NW = 4 -> 2, 3 -> 2, 2 -> 4, 1 -> 8 workgroups per CU
+    if (const char* v = getenv("DMF_V2_PER_CU")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (experiments)
     const int64_t nblk = (N + 15) / 16;
     const int64_t g = 256 * per_cu;
     return (int)(nblk < g ? nblk : g);
@@ -380,7 +455,11 @@ static hipError_t launch_v2_t(const double* V, const unsigned short* D16, int SD
     const int grid = rowpass_v2_grid(N, S);
     *grid_out = grid;
     hipLaunchKernelGGL((k_rowpass_v2<NKC, NU>), dim3(grid), dim3(NW * 64), lds, st, V, D16, SD, Rtp, alpha, u, u_prev,
-                       state, N, S, n_c, n_iter2, mode, slab, u2_partials);
+                       state, N, S, n_c, n_iter2, mode, slab, u2_partials
+#ifdef DMF_STAMPS
+                       , (unsigned long long*)nullptr
+#endif
+                       );
     return hipGetLastError();
 }
 

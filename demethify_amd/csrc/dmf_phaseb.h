@@ -42,6 +42,13 @@ __device__ __forceinline__ double f_sub_clamp01(double a, double b) {
     return r;
 }
 
+// clip(a + b, 0, 1) in one instruction (VOP3 clamp modifier; a NaN would come out as 0 instead of NaN)
+__device__ __forceinline__ double f_add_clamp01(double a, double b) {
+    double r;
+    asm("v_add_f64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // clip(a * b + c, 0, 1) in one instruction: the VOP3 clamp modifier clamps an FP result to [0, 1]
 // (np.clip(x, 0, 1) of deconvolution.py:88; a NaN would come out as 0 instead of NaN)
 __device__ __forceinline__ double f_fma_clamp01(double a, double b, double c) {
