@@ -10,13 +10,16 @@ re-partitioned by CpG range with one all-to-all.
 """
 from __future__ import annotations
 
+import queue
+import threading
+
 import numpy as np
 import pandas as pd
 
 from . import _lib as L
 from . import shard
 from .deconvolution import init_BSSMF_md, init_BSSMF_md_p, solve_problem
-from .device import Problem, get_context
+from .device import Problem, Solver, get_context
 from .init_func import wls_intercept
 
 __all__ = ["bt_ci", "bootstrap_seed_sequence", "bootstrap_row_indices"]
@@ -35,6 +38,19 @@ def bootstrap_seed_sequence(seed, n_bootstrap):
 def bootstrap_row_indices(seed, n_rows):
     """Row indices sklearn's ``resample`` draws for ``random_state=seed`` (bootstrap.py:28)."""
     return np.random.RandomState(seed).randint(0, n_rows, size=(n_rows,))
+
+
+def _device_stack(n_local, width):
+    """(n_local, width) float64 buffer on this process's GPU for the replicate profiles (B x N x n_u doubles: 16 GB at
+    500 x 1e6 x 4, held in HBM instead of travelling to the host and back for the percentiles), or None when PyTorch
+    is not importable (the stack then lives on the host, as upstream's)."""
+    try:
+        import torch
+    except ImportError:  # pragma: no cover - torch is part of the target image
+        return None
+    if not torch.cuda.is_available() or n_local == 0:
+        return None
+    return torch.empty((n_local, width), dtype=torch.float64, device=torch.device("cuda", get_context().device))
 
 
 def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, n_iter1, n_iter2, tol, header,
@@ -63,22 +79,51 @@ def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, 
                                     for k in range(n_samples)], axis=1)
             local.append((i, (None, props)))
     else:
+        # Replicate i + 1's host work (MT19937 index draw of N rows, uniform N x n_u + Dirichlet init: tens of
+        # milliseconds at 1e6 rows) is drawn by a worker thread while the GPU solves replicate i.  Each replicate has
+        # its own RandomState(seed_i) for the rows (what sklearn's resample does) and the init re-seeds numpy's global
+        # stream with seed_i (deconvolution.py:41), so the draws do not depend on the order the threads run in; only the
+        # worker touches the global stream while the loop is active.
+        mine = shard.my_items(n_bootstrap, rank, world)
+        feed: queue.Queue = queue.Queue(maxsize=2)
+
+        def draw():
+            try:
+                for i in mine:
+                    idx = bootstrap_row_indices(seeds[i], n_rows)
+                    needs_data = init_option == "uniform"
+                    mf = meth_f[idx] if needs_data else np.broadcast_to(meth_f[:1], meth_f.shape)
+                    ct = counts[idx] if needs_data else np.broadcast_to(counts[:1], counts.shape)
+                    rf = ref[idx] if needs_data else np.broadcast_to(ref[:1], ref.shape)
+                    if purity_frac is not None:
+                        u0, _, a0 = init_BSSMF_md_p(init_option, mf, ct, rf, n_u, purity_frac, seed=seeds[i],
+                                                    rb_alg=wls_intercept)
+                    else:
+                        u0, _, a0 = init_BSSMF_md(init_option, mf, ct, rf, n_u, rb_alg=wls_intercept, seed=seeds[i])
+                    feed.put((i, idx, u0, a0))
+            except BaseException as exc:  # hand the failure to the consumer instead of dying silently
+                feed.put(exc)
+
+        worker = threading.Thread(target=draw, daemon=True)
+        u_stack = _device_stack(len(mine), n_rows * n_u)  # replicate profiles stay in HBM when torch is there
         with Problem(get_context(), meth_f, counts, ref) as full:
-            for i in shard.my_items(n_bootstrap, rank, world):
-                idx = bootstrap_row_indices(seeds[i], n_rows)
-                needs_data = init_option == "uniform"
-                mf = meth_f[idx] if needs_data else np.broadcast_to(meth_f[:1], meth_f.shape)
-                ct = counts[idx] if needs_data else np.broadcast_to(counts[:1], counts.shape)
-                rf = ref[idx] if needs_data else np.broadcast_to(ref[:1], ref.shape)
-                if purity_frac is not None:
-                    u0, _, a0 = init_BSSMF_md_p(init_option, mf, ct, rf, n_u, purity_frac, seed=seeds[i],
-                                                rb_alg=wls_intercept)
-                else:
-                    u0, _, a0 = init_BSSMF_md(init_option, mf, ct, rf, n_u, rb_alg=wls_intercept, seed=seeds[i])
-                with full.gather(idx) as resampled:
-                    u, alpha = solve_problem(resampled, u0, a0, L.DMF_MODE_PARTIAL, n_iter1, n_iter2, tol,
-                                             purity=purity_frac)
-                local.append((i, (u, alpha)))
+            worker.start()
+            for j in range(len(mine)):
+                item = feed.get()
+                if isinstance(item, BaseException):
+                    raise item
+                i, idx, u0, a0 = item
+                with full.gather(idx) as resampled, Solver(resampled, u0, a0, L.DMF_MODE_PARTIAL) as s:
+                    if purity_frac is not None:
+                        s.set_purity(purity_frac)
+                    s.step(n_iter1, n_iter2, tol)
+                    if u_stack is not None:
+                        s.copy_u_to(u_stack[j])
+                        local.append((i, (None, s.get_alpha())))
+                    else:
+                        u, alpha, _, _ = s.get()
+                        local.append((i, (u, alpha)))
+            worker.join()
     # proportions (K x S per replicate, KB-sized) go to every rank
     merged = shard.gather_objects([(i, pa) for i, (_, pa) in local])
     props_stack = np.stack([pa for _, pa in merged])  # (B, K, S)
@@ -105,8 +150,10 @@ def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, 
         # Profile estimates: B x N x n_u doubles (16 GB at 500 x 1e6 x 4).  Each rank holds the replicates it
         # ran; one all-to-all re-partitions them by CpG range and every rank takes the percentiles of its
         # range on its GPU (shard.percentile_over_replicates); rank 0 writes the CSV.
-        local_u = (np.stack([pu.reshape(-1) for _, (pu, _) in local]) if local
-                   else np.empty((0, n_rows * n_u)))
+        if u_stack is not None:
+            local_u = u_stack
+        else:
+            local_u = (np.stack([pu.reshape(-1) for _, (pu, _) in local]) if local else np.empty((0, n_rows * n_u)))
         bounds = shard.percentile_over_replicates(local_u, n_bootstrap, q, get_context().percentile_axis0)
         if bounds is not None:
             lower_u, upper_u = (b.reshape(n_rows, n_u) for b in bounds)  # by resampled position, as upstream

@@ -313,6 +313,17 @@ int problem_finalize(dmf_problem* p) {
     return DMF_OK;
 }
 
+// cost_f_w of (u, alpha) on the problem's data: the column-resident kernel when the shape allows, else the generic one
+hipError_t enqueue_cost(dmf_context* ctx, const dmf_problem* p, const double* u, const double* alpha, int n_u,
+                        double* scratch, double* out) {
+    const bool rtp_ok = p->n_c == 0 || p->Rtp != nullptr;
+    if ((ctx->generic_level == 0 || ctx->generic_level == 3 || ctx->generic_level == 4) && rtp_ok &&
+        dmf::cost_cols_supported((int)p->S, (int)p->n_c, n_u))
+        return dmf::launch_cost_cols(p->V, p->D, p->D16, p->SD, p->Rtp, u, alpha, p->N, (int)p->S, (int)p->n_c, n_u,
+                                     scratch, out, ctx->stream);
+    return dmf::launch_cost(p->V, p->D, p->Rt, u, alpha, p->N, (int)p->S, (int)p->n_c, n_u, scratch, out, ctx->stream);
+}
+
 int check_ctx(dmf_context* ctx) {
     if (ctx == nullptr) return DMF_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -829,8 +840,7 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     if (e == hipSuccess) e = dmf::launch_sumsq_f64(s->u, N * n_u, ctx->scratch, &s->state->u_norm2, nullptr, ctx->stream);
     if (e == hipSuccess) {
         FamilyScope scope(ctx, DMF_KERNEL_COST);
-        e = dmf::launch_cost(p->V, p->D, p->Rt, s->u, s->alpha, N, (int)S, (int)n_c, (int)n_u,
-                             ctx->scratch + 1024, &s->state->cf, ctx->stream);
+        e = enqueue_cost(ctx, p, s->u, s->alpha, (int)n_u, ctx->scratch + 1024, &s->state->cf);
     }
     if (e == hipSuccess) e = dmf::launch_init_state(s->state, p->consts, s->alpha, (int)S, (int)n_c, (int)n_u, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host job vectors go out of scope
@@ -901,8 +911,7 @@ int dmf_solver_cost(dmf_solver* s, double* out_cost) {
     const dmf_problem* p = s->p;
     {
         FamilyScope scope(ctx, DMF_KERNEL_COST);
-        HIP_TRY(dmf::launch_cost(p->V, p->D, p->Rt, s->u, s->alpha, p->N, (int)p->S, (int)p->n_c, (int)s->n_u,
-                                 ctx->scratch + 1024, ctx->scratch + 3072, ctx->stream));
+        HIP_TRY(enqueue_cost(ctx, p, s->u, s->alpha, (int)s->n_u, ctx->scratch + 1024, ctx->scratch + 3072));
     }
     HIP_TRY(hipMemcpyAsync(out_cost, ctx->scratch + 3072, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -996,8 +1005,7 @@ int dmf_cost(dmf_context* ctx, const dmf_problem* p, const double* u, int64_t n_
         hipError_t e = pool_alloc(ctx, (void**)&dout, sizeof(double));
         if (e == hipSuccess) {
             FamilyScope scope(ctx, DMF_KERNEL_COST);
-            e = dmf::launch_cost(p->V, p->D, p->Rt, du, da, p->N, (int)p->S, (int)p->n_c, (int)n_u,
-                                 ctx->scratch, dout, ctx->stream);
+            e = enqueue_cost(ctx, p, du, da, (int)n_u, ctx->scratch + 1024, dout);
         }
         if (e == hipSuccess) e = hipMemcpyAsync(out_cost, dout, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -73,6 +73,13 @@ hipError_t launch_cost(const double* V, const double* D, const double* Rt, const
                        const double* alpha, int64_t N, int S, int n_c, int n_u,
                        double* scratch, double* out, hipStream_t st);
 
+// the same cost for n_c <= 16, n_u <= 4 with the lane's alpha column in registers: Rtp = padded R_trunc copy,
+// D16 (u16 counts, row stride SD) is read instead of D when it is not null
+bool cost_cols_supported(int S, int n_c, int n_u);
+hipError_t launch_cost_cols(const double* V, const double* D, const unsigned short* D16, int SD, const double* Rtp,
+                            const double* u, const double* alpha, int64_t N, int S, int n_c, int n_u, double* scratch,
+                            double* out, hipStream_t st);
+
 // generic weighted Gram accumulation over the extended row vector x = (Rt, u, v)
 hipError_t launch_gram(const double* V, const double* D, const double* Rt, const double* u,
                        int64_t N, int S, int n_c, int n_u, GramJobTable jobs,

@@ -210,6 +210,107 @@ __global__ __launch_bounds__(256) void k_cost(const double* __restrict__ V, cons
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// Column-resident variant for the shapes of the fast solver paths (n_c <= 16, n_u <= 4): lane = sample, the lane's
+// alpha column lives in registers, a row's profile values (R_trunc padded copy, u) are wave-uniform scalar loads that
+// feed v_fma_f64 directly, eight rows of V / D are in flight per wave.  HBM-bound: one read of V and of the counts
+// (u16 copy when the problem has one: 10 instead of 16 bytes per element).  Same per-element arithmetic as k_cost.
+template <int NKC, int NU, bool D16>
+__global__ __launch_bounds__(256) void k_cost_cols(const double* __restrict__ V, const void* __restrict__ Dv, int SD,
+                                                   const double* __restrict__ Rtp, const double* __restrict__ u,
+                                                   const double* __restrict__ alpha, int64_t N, int S, int n_c,
+                                                   double* __restrict__ partial) {
+    constexpr int NCT = 4 * NKC;
+    constexpr int kRows = 8;
+    __shared__ double red[4];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int s = blockIdx.y * 64 + lane;
+    const bool active = s < S;
+    const int sc = active ? s : S - 1;
+    double ak[NCT > 0 ? NCT : 1], aj[NU > 0 ? NU : 1];
+#pragma unroll
+    for (int k = 0; k < NCT; ++k) ak[k] = k < n_c ? alpha[(int64_t)k * S + sc] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) aj[j] = alpha[(int64_t)(n_c + j) * S + sc];
+    const double* __restrict__ Df = reinterpret_cast<const double*>(Dv);
+    const unsigned short* __restrict__ Dh = reinterpret_cast<const unsigned short*>(Dv);
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t i0 = (int64_t)blockIdx.x * 4 + wave; i0 < N; i0 += kRows * stride) {
+        double v[kRows], d[kRows];
+        int64_t row[kRows];
+#pragma unroll
+        for (int x = 0; x < kRows; ++x) {
+            const int64_t i = i0 + x * stride;
+            row[x] = i < N ? i : N - 1;
+            v[x] = V[row[x] * S + sc];
+            if constexpr (D16) d[x] = (double)Dh[row[x] * SD + sc];
+            else d[x] = Df[row[x] * S + sc];
+            if (i >= N) d[x] = 0.0;  // rows past N weigh nothing
+        }
+#pragma unroll
+        for (int x = 0; x < kRows; ++x) {
+            const double* __restrict__ rt_row = Rtp + row[x] * NCT;
+            const double* __restrict__ u_row = u + row[x] * NU;
+            double pred = 0.0;
+#pragma unroll
+            for (int k = 0; k < NCT; ++k) pred = fma(rt_row[k], ak[k], pred);
+#pragma unroll
+            for (int j = 0; j < NU; ++j) pred = fma(u_row[j], aj[j], pred);
+            const double e = v[x] - pred;
+            acc = fma(d[x] * e, e, acc);
+        }
+    }
+    if (!active) acc = 0.0;
+    const double tot = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
+bool cost_cols_supported(int S, int n_c, int n_u) { return n_c <= 16 && n_u >= 0 && n_u <= 4 && n_c + n_u >= 1; }
+
+template <int NKC, int NU>
+static hipError_t launch_cost_cols_t(const double* V, const double* D, const unsigned short* D16, int SD, const double* Rtp,
+                                     const double* u, const double* alpha, int64_t N, int S, int n_c, double* scratch,
+                                     double* out, hipStream_t st) {
+    const int ny = (S + 63) / 64;
+    int64_t want = (N + 4 * 8 - 1) / (4 * 8);
+    int nbx = (int)(want < 1 ? 1 : want);
+    const int cap = 1024 / ny;  // scratch: 1024 partials
+    if (nbx > cap) nbx = cap;
+    if (D16 != nullptr)
+        hipLaunchKernelGGL((k_cost_cols<NKC, NU, true>), dim3(nbx, ny), dim3(256), 0, st, V, (const void*)D16, SD, Rtp, u,
+                           alpha, N, S, n_c, scratch);
+    else
+        hipLaunchKernelGGL((k_cost_cols<NKC, NU, false>), dim3(nbx, ny), dim3(256), 0, st, V, (const void*)D, S, Rtp, u, alpha,
+                           N, S, n_c, scratch);
+    hipLaunchKernelGGL(k_reduce_final<1>, dim3(1), dim3(256), 0, st, scratch, nbx * ny, out, (const int*)nullptr);
+    return hipGetLastError();
+}
+
+template <int NKC>
+static hipError_t launch_cost_cols_nkc(int n_u, const double* V, const double* D, const unsigned short* D16, int SD,
+                                       const double* Rtp, const double* u, const double* alpha, int64_t N, int S, int n_c,
+                                       double* scratch, double* out, hipStream_t st) {
+    switch (n_u) {
+#define DMF_CASE(NU_) \
+    case NU_: return launch_cost_cols_t<NKC, NU_>(V, D, D16, SD, Rtp, u, alpha, N, S, n_c, scratch, out, st);
+        DMF_CASE(0) DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4)
+#undef DMF_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_cost_cols(const double* V, const double* D, const unsigned short* D16, int SD, const double* Rtp,
+                            const double* u, const double* alpha, int64_t N, int S, int n_c, int n_u, double* scratch,
+                            double* out, hipStream_t st) {
+    switch ((n_c + 3) / 4) {
+#define DMF_NKC(X) \
+    case X: return launch_cost_cols_nkc<X>(n_u, V, D, D16, SD, Rtp, u, alpha, N, S, n_c, scratch, out, st);
+        DMF_NKC(0) DMF_NKC(1) DMF_NKC(2) DMF_NKC(3) DMF_NKC(4)
+#undef DMF_NKC
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_cost(const double* V, const double* D, const double* Rt, const double* u,
                        const double* alpha, int64_t N, int S, int n_c, int n_u,
                        double* scratch, double* out, hipStream_t st) {

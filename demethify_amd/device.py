@@ -315,6 +315,20 @@ class Solver:
         L.check(self._lib.dmf_solver_describe(self._h, int(n_iter2), buf, len(buf)), "dmf_solver_describe")
         return buf.value.decode()
 
+    def get_alpha(self):
+        """The current proportions (K x S) as a fresh host array; u stays on the device."""
+        alpha = np.empty((self.K, self.problem.S), dtype=np.float64)
+        L.check(self._lib.dmf_solver_get(self._h, 0, None, _ptr(alpha), None, None), "dmf_solver_get")
+        return alpha
+
+    def copy_u_to(self, tensor):
+        """Copy the current profile estimate u (N x n_u, C order) into a float64 CUDA torch tensor of N * n_u elements
+        on the context's GPU (device to device): the bootstrap keeps its replicate stack in HBM."""
+        if not (_is_torch(tensor) and tensor.is_cuda and tensor.is_contiguous() and tensor.numel() == self.problem.N * self.n_u
+                and tensor.element_size() == 8 and tensor.device.index == self.problem.ctx.device):
+            raise ValueError("copy_u_to needs a contiguous float64 CUDA tensor of N * n_u elements on the context's GPU")
+        L.check(self._lib.dmf_solver_get(self._h, L.DMF_PTR_DEVICE, _ptr(tensor), None, None, None), "dmf_solver_get")
+
     def get_cost(self):
         """(cost, iterations) of the current iterate without copying u / alpha back."""
         cost, it = C.c_double(), C.c_int64()

@@ -124,12 +124,17 @@ def percentile_over_replicates(local_stack, n_items, q, percentile_fn):
     columns of range r from every rank: n_items x m_r values), each rank reduces its range, and rank 0
     collects the (len(q), m) result (None elsewhere)."""
     rank, world, dev = dist_state()
+    on_device = type(local_stack).__module__.startswith("torch")  # the bootstrap's HBM-resident stack
     if world == 1:
-        return np.asarray(percentile_fn(np.ascontiguousarray(local_stack), q))
+        out = percentile_fn(local_stack if on_device else np.ascontiguousarray(local_stack), q)
+        return out.cpu().numpy() if hasattr(out, "cpu") else np.asarray(out)
     import torch
     import torch.distributed as dist
 
-    local = torch.as_tensor(np.ascontiguousarray(local_stack, dtype=np.float64)).to(dev)
+    if on_device:
+        local = local_stack if dev.type == "cuda" else local_stack.cpu()
+    else:
+        local = torch.as_tensor(np.ascontiguousarray(local_stack, dtype=np.float64)).to(dev)
     n_local, m = local.shape
     counts = [len(my_items(n_items, r, world)) for r in range(world)]
     assert counts[rank] == n_local, (counts, rank, n_local)
@@ -140,6 +145,8 @@ def percentile_over_replicates(local_stack, n_items, q, percentile_fn):
     dist.all_to_all_single(recv, send, output_split_sizes=[c * (b - a) for c in counts],
                            input_split_sizes=[n_local * (hi - lo) for lo, hi in ranges])
     del send, local
+    # rank r's pieces arrive grouped by source rank; replicate i ran on rank i mod world: back to replicate order is
+    # not needed for a percentile (a permutation of axis 0)
     mine = percentile_fn(recv.view(n_items, b - a), q) if b > a else np.empty((len(np.atleast_1d(q)), 0))
     mine = mine.cpu().numpy() if hasattr(mine, "cpu") else np.asarray(mine)
     parts = gather_objects([(rank, mine)], root_only=True)

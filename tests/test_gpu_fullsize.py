@@ -97,3 +97,45 @@ def test_headline_size_properties(ctx):
         finally:
             ctx.set_generic(0)
         assert np.abs(a3 - a1).max() < 1e-9 and np.abs(u3 - u1).max() < 1e-9 and c3 == pytest.approx(c1, rel=1e-10)
+
+
+def test_bootstrap_building_blocks_at_headline_size(ctx):
+    """BASELINE.json configs[3] (1e6 CpG x 256 samples, --confidence 95 500) piece by piece: the device row gather of one
+    resample (bootstrap.py:28 = RandomState(seed).randint applied to meth_f, counts, ref alike) against the oracle on
+    a 50 000-row slice gathered the same way, a permutation followed by its inverse (bit-for-bit the original
+    problem), and the percentile over a 500-replicate stack of 1e6 positions against numpy on sampled columns."""
+    torch = pytest.importorskip("torch")
+    from bench import make_inputs_on_device
+    from demethify_amd.device import Problem
+
+    N, S, n_c, n_u = 1_000_000, 256, 12, 4
+    dev = torch.device("cuda", 0)
+    V, D, Rt = make_inputs_on_device(torch, dev, N, S, n_c, n_u, seed=0)
+    rs = np.random.RandomState(5)
+    u = rs.uniform(size=(N, n_u))
+    alpha = rs.dirichlet(np.ones(n_c + n_u), S).T
+    idx = osol.bootstrap_indices(11, N)  # what sklearn's resample(random_state=11) draws
+    with Problem(ctx, V, D, Rt) as p:
+        n_s = 50_000
+        it = torch.from_numpy(idx[:n_s]).to(dev)
+        Vs, Ds, Rs = V[it].cpu().numpy(), D[it].cpu().numpy().astype(np.int64), Rt[it].cpu().numpy()
+        want = osol.weighted_cost(Vs, np.c_[Rs, u[:n_s]], alpha, Ds)
+        with p.gather(idx[:n_s]) as g:
+            assert g.cost(u[:n_s], alpha) == pytest.approx(want, rel=1e-12)
+        with p.gather(idx) as g:  # the full resample: 1e6 gathered rows; its first 50 000 rows are the slice above
+            full = g.cost(u, alpha)
+            assert np.isfinite(full) and full > want
+        base = p.cost(u, alpha)
+        perm = rs.permutation(N)
+        inv = np.argsort(perm)
+        with p.gather(perm) as g1, g1.gather(inv) as g2:
+            assert g2.cost(u, alpha) == base  # same rows in the same order: bit for bit
+            # and a pure reordering of the rows changes the sum only in its rounding
+            assert g1.cost(u[perm], alpha) == pytest.approx(base, rel=1e-12)
+    del V, D, Rt
+    x = torch.rand((500, 1_000_000), dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    q = [2.5, 97.5]
+    got = ctx.percentile_axis0(x, q)
+    cols = np.r_[0:1000, 499_000:500_000, 999_000:1_000_000]
+    want_q = np.percentile(x[:, torch.from_numpy(cols).to(dev)].cpu().numpy(), q, axis=0)
+    assert np.array_equal(got[:, torch.from_numpy(cols).to(dev)].cpu().numpy(), want_q)  # numpy's "linear" method, bit for bit
