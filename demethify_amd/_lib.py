@@ -51,6 +51,11 @@ SIGNATURES = {
     "dmf_solver_cost": (C.c_int, [_p, _dbl_p]),
     "dmf_solver_destroy": (C.c_int, [_p]),
     "dmf_solver_describe": (C.c_int, [_p, _i64, C.c_char_p, _i64]),
+    "dmf_table_scan": (C.c_int, [C.c_char_p, C.c_char, C.POINTER(_i64), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                 C.POINTER(C.c_int)]),
+    "dmf_table_read": (C.c_int, [C.c_char_p, C.c_char, C.c_int, C.c_int, _i64, _p, _i64, C.c_double, _p, _i64, C.c_int]),
+    "dmf_host_alloc": (_p, [C.c_size_t, C.POINTER(C.c_int)]),
+    "dmf_host_free": (None, [_p, C.c_int]),
     "dmf_solve": (C.c_int, [_p, _p, _p, _p, _i64, C.c_int, _i64, _i64, C.c_double, C.c_int, _p, _p,
                             _dbl_p, C.POINTER(_i64)]),
 }

@@ -55,6 +55,7 @@ struct dmf_context {
     int generic_level = 0;  // 0 fused row pass, 1 any-shape Gram-form kernels, 2 schedule-faithful u steps,
                             // 3 separate MFMA row pass + one-pass Gram (the pieces the fused kernel is made of)
     double* scratch = nullptr;  // 4096 doubles of reduction scratch
+    hipMemPool_t pool = nullptr;  // the context's own stream-ordered pool (the device's default pool is not touched)
     FamilyClock clocks[DMF_KERNEL_FAMILIES];
 };
 
@@ -150,10 +151,11 @@ struct FamilyScope {
     }
 };
 
-// Device buffers come from the device's stream-ordered memory pool on the context's stream.  The pool keeps
-// what is freed (release threshold raised in dmf_context_create), so the multi-GB buffers of a problem or a
-// solver that is destroyed and re-created with the same sizes -- every bootstrap replicate does that -- are
-// handed back without a trip to the driver (hipMalloc / hipFree of 2 GB cost tens of milliseconds each).
+// Device buffers come from a stream-ordered memory pool OF THE CONTEXT'S OWN on the context's stream.  The pool keeps
+// what is freed (release threshold raised in dmf_context_create; the device's default pool, which other users of a
+// borrowed device share, is left alone), so the multi-GB buffers of a problem or a solver that is destroyed and
+// re-created with the same sizes -- every bootstrap replicate does that -- are handed back without a trip to the
+// driver (hipMalloc / hipFree of 2 GB cost tens of milliseconds each).
 static bool pool_enabled() {  // DEMETHIFY_NO_POOL=1: plain hipMalloc / hipFree (debugging aid)
     static const bool on = [] {
         const char* v = getenv("DEMETHIFY_NO_POOL");
@@ -162,12 +164,12 @@ static bool pool_enabled() {  // DEMETHIFY_NO_POOL=1: plain hipMalloc / hipFree 
     return on;
 }
 static hipError_t pool_alloc(dmf_context* ctx, void** p, size_t bytes) {
-    if (!pool_enabled()) return hipMalloc(p, bytes);
-    return hipMallocAsync(p, bytes, ctx->stream);
+    if (!pool_enabled() || ctx->pool == nullptr) return hipMalloc(p, bytes);
+    return hipMallocFromPoolAsync(p, bytes, ctx->pool, ctx->stream);
 }
 static void pool_free(dmf_context* ctx, void* p) {
     if (p == nullptr) return;
-    if (!pool_enabled()) {
+    if (!pool_enabled() || ctx->pool == nullptr) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(p);
     } else {
@@ -559,11 +561,21 @@ int dmf_context_create(int device, void* stream, dmf_context** out) {
         delete ctx;
         return hip_fail(e, "hipMalloc(scratch)", __LINE__);
     }
-    // keep freed pool memory for the next problem / solver of the same size (see pool_alloc)
-    hipMemPool_t pool = nullptr;
-    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool != nullptr) {
-        uint64_t keep = UINT64_MAX;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    // a pool of the context's own that keeps freed memory for the next problem / solver of the same size (see
+    // pool_alloc); if the runtime cannot create one, plain hipMalloc / hipFree are used
+    if (pool_enabled()) {
+        hipMemPoolProps props = {};
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = device;
+        if (hipMemPoolCreate(&ctx->pool, &props) == hipSuccess && ctx->pool != nullptr) {
+            uint64_t keep = UINT64_MAX;
+            (void)hipMemPoolSetAttribute(ctx->pool, hipMemPoolAttrReleaseThreshold, &keep);
+        } else {
+            ctx->pool = nullptr;
+            (void)hipGetLastError();
+        }
     }
     *out = ctx;
     return DMF_OK;
@@ -578,8 +590,7 @@ int dmf_context_destroy(dmf_context* ctx) {
         for (auto ev : c.stop) hipEventDestroy(ev);
     }
     hipFree(ctx->scratch);
-    hipMemPool_t pool = nullptr;  // hand the cached buffers back to the driver
-    if (hipDeviceGetDefaultMemPool(&pool, ctx->device) == hipSuccess && pool != nullptr) (void)hipMemPoolTrimTo(pool, 0);
+    if (ctx->pool != nullptr) (void)hipMemPoolDestroy(ctx->pool);  // hands the cached buffers back to the driver
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return DMF_OK;

@@ -9,6 +9,10 @@ costs far more wall-clock than the solve.  Here the same parser (so the parsed v
   * and, with torch.distributed initialised, on a 1 / world share of the files per rank, the parsed columns being
     exchanged as tensors (one broadcast per rank: RCCL over xGMI with the nccl backend) instead of every rank
     parsing every file.
+Single-process runs first try the library's own columnar reader (csrc/dmf_tables.hip: memory-mapped, multi-threaded,
+the two columns parsed straight into page-locked (N x S) matrices with the arithmetic of pandas' C parser, so the
+values are bit-identical); any file that reader declines (NA spellings, quotes, fractional coverage, --fillna) sends
+the whole input through the pandas path.
 """
 from __future__ import annotations
 
@@ -88,6 +92,77 @@ def _stack(columns, n_rows, dtype):
     return out
 
 
+def _host_matrix(shape, dtype):
+    """(N, S) array in page-locked host memory when the library can provide it (the H2D upload of the problem then
+    needs no staging copy), plain numpy memory otherwise."""
+    import ctypes as C
+    import weakref
+
+    from . import _lib as L
+
+    lib = L.load()
+    n_bytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    pinned = C.c_int(0)
+    ptr = lib.dmf_host_alloc(n_bytes, C.byref(pinned)) if n_bytes else None
+    if not ptr:
+        return np.empty(shape, dtype=dtype)
+    buf = (C.c_char * n_bytes).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+    weakref.finalize(buf, lib.dmf_host_free, ptr, pinned.value)  # released with the last view of the buffer
+    return arr
+
+
+def read_samples_native(paths, bedmethyl: bool):
+    """All sample files through the library's columnar reader -> (meth_f, counts) or None if any file needs pandas."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    from . import _lib as L
+
+    try:
+        lib = L.load()
+    except (ImportError, OSError):
+        return None
+    sep = b"\t" if bedmethyl else b","
+    scans = []
+    for path in paths:
+        n, c_pm, c_cov, n_cols = C.c_int64(), C.c_int(), C.c_int(), C.c_int()
+        st = lib.dmf_table_scan(os.fsencode(path), sep, C.byref(n), C.byref(c_pm), C.byref(c_cov), C.byref(n_cols))
+        if st != L.DMF_OK or c_pm.value < 0:
+            return None
+        single = (not bedmethyl) and n_cols.value == 1
+        if c_cov.value < 0 and not single:
+            return None  # pandas raises KeyError('valid_coverage') there: let it
+        scans.append((n.value, c_pm.value, c_cov.value))
+    n_rows = scans[0][0]
+    if n_rows == 0 or any(s[0] != n_rows for s in scans):
+        return None  # pandas' error message for ragged inputs
+    S = len(paths)
+    meth_f = _host_matrix((n_rows, S), np.float64)
+    counts = _host_matrix((n_rows, S), np.int64)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        cores = os.cpu_count() or 1
+    files_at_once = max(1, min(S, cores))
+    threads_per_file = max(1, cores // files_at_once)
+
+    def one(k):
+        _, c_pm, c_cov = scans[k]
+        f_ptr = meth_f.ctypes.data + 8 * k
+        c_ptr = counts.ctypes.data + 8 * k
+        st = lib.dmf_table_read(os.fsencode(paths[k]), sep, c_pm, c_cov, n_rows, C.c_void_p(f_ptr), S,
+                                100.0 if bedmethyl else 1.0, C.c_void_p(c_ptr), S, threads_per_file)
+        if st == L.DMF_OK and c_cov < 0:
+            counts[:, k] = 1  # a single-column csv: coverage 1, demethify.py:137-138
+        return st
+
+    with ThreadPoolExecutor(max_workers=files_at_once) as pool:  # ctypes releases the GIL during the call
+        if any(st != L.DMF_OK for st in pool.map(one, range(S))):
+            return None
+    return meth_f, counts
+
+
 def env_rank_world():
     """(rank, world) of a torch.distributed.run launch, from the environment: known before the process group (and
     with it the GPU runtime) exists."""
@@ -100,6 +175,10 @@ def parse_share(paths, bedmethyl: bool, fillna: bool):
     that has not touched the GPU (a fork of a process that holds a HIP runtime and RCCL threads inherits locked
     mutexes and the KFD file descriptor)."""
     rank, world = env_rank_world()
+    if world == 1 and not fillna and os.environ.get("DEMETHIFY_PANDAS_READER") != "1":
+        native = read_samples_native(paths, bedmethyl)
+        if native is not None:
+            return ("native", native)
     mine = shard.my_items(len(paths), rank, world)
     return _read_many([paths[i] for i in mine], bedmethyl, fillna)
 
@@ -109,6 +188,10 @@ def read_samples(paths, bedmethyl: bool, fillna: bool, parsed=None):
     per-file columns (same dtypes: counts stay int64 unless a file forces float).  ``parsed`` = the result of an
     earlier parse_share() of the same arguments on this rank (the CLI parses before it initialises the GPU)."""
     rank, world, dev = shard.dist_state()
+    if parsed is None and world == 1:
+        parsed = parse_share(paths, bedmethyl, fillna)
+    if isinstance(parsed, tuple) and len(parsed) == 2 and parsed[0] == "native":
+        return parsed[1]
     if parsed is None:
         mine = shard.my_items(len(paths), rank, world)
         parsed = _read_many([paths[i] for i in mine], bedmethyl, fillna)

@@ -22,6 +22,7 @@
 #ifndef DEMETHIFY_HIP_H
 #define DEMETHIFY_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -157,6 +158,23 @@ int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t
 int dmf_solve(dmf_context* ctx, const dmf_problem* p, const double* u0, const double* alpha0,
               int64_t n_u, int mode, int64_t n_iter1, int64_t n_iter2, double tol, int flags,
               double* out_u, double* out_alpha, double* out_cost, int64_t* out_iters);
+
+/* ---- input tables (host side) ---------------------------------------------------------------
+ * demethify/demethify.py:103-143 reads each sample file with pandas.read_csv and stacks its `percent_modified` and
+ * `valid_coverage` columns.  dmf_table_scan finds the two columns by header name and counts the data rows;
+ * dmf_table_read parses them (n_threads threads) into strided destinations: out_freq[row * stride_freq] =
+ * value / divide_by (100 for bedmethyl percentages, 1 for csv fractions), out_cov[row * stride_cov] = coverage
+ * (col_valid_coverage < 0: no such column, out_cov untouched).  Values are bit-identical to pandas' default parser; any
+ * content that parser treats specially (quotes, NA spellings, blank lines, non-integer coverage) yields
+ * DMF_ERR_UNSUPPORTED and the caller reads that file with pandas.  dmf_host_alloc returns page-locked host memory when a
+ * GPU runtime is present (*pinned = 1), plain memory otherwise. */
+int dmf_table_scan(const char* path, char sep, int64_t* n_rows, int* col_percent_modified, int* col_valid_coverage,
+                   int* n_cols);
+int dmf_table_read(const char* path, char sep, int col_percent_modified, int col_valid_coverage, int64_t n_rows,
+                   double* out_freq, int64_t stride_freq, double divide_by, int64_t* out_cov, int64_t stride_cov,
+                   int n_threads);
+void* dmf_host_alloc(size_t bytes, int* pinned);
+void dmf_host_free(void* p, int pinned);
 
 #ifdef __cplusplus
 }

@@ -113,3 +113,64 @@ def test_table_reader_equals_upstream_loop(tmp_path, monkeypatch):
     short.write_text("percent_modified,valid_coverage\n0.1,7\n")
     with pytest.raises(ValueError):
         tables.read_samples([str(two), str(short)], False, False)
+
+
+def _pandas_tables(paths, bedmethyl):
+    import os
+
+    from demethify_amd import tables
+
+    os.environ["DEMETHIFY_PANDAS_READER"] = "1"
+    try:
+        return tables.read_samples(paths, bedmethyl, False)
+    finally:
+        del os.environ["DEMETHIFY_PANDAS_READER"]
+
+
+def test_native_table_reader_is_bit_identical_to_pandas(tmp_path):
+    """csrc/dmf_tables.hip against the pandas path (demethify.py:103-143) on the reference's own bedmethyl files and on
+    synthetic tables with every number format the parser has a branch for."""
+    from conftest import UPSTREAM
+    from demethify_amd import tables
+
+    golden = [str(UPSTREAM / "output_gen" / f"sample{i}.bed") for i in range(1, 11)]
+    golden.append(str(UPSTREAM / "config1" / "bed2_intersect.bed"))
+    for group in (golden[:10], golden[10:]):
+        got = tables.read_samples_native(group, True)
+        want = _pandas_tables(group, True)
+        assert got is not None and got[1].dtype == want[1].dtype == np.int64
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        assert got[0].flags.c_contiguous and got[0].shape == want[0].shape
+    rs = np.random.RandomState(3)
+    n = 5000
+    for k, sep in enumerate(["\t", ","]):
+        files = []
+        for j in range(3):
+            x = rs.uniform(0, 100 if sep == "\t" else 1, n)
+            texts = []
+            for i, v in enumerate(x):  # 17-digit repr, short decimals, integers, exponent notation, long digit strings
+                texts.append([repr(float(v)), f"{v:.2f}", f"{v:.6f}", str(int(v)), f"{v:.10e}", f"{v:.20f}", f"{v / 1e5:.3e}"][i % 7])
+            cov = rs.poisson(30, n) + (0 if j else 1)
+            path = tmp_path / f"t{k}{j}.txt"
+            with open(path, "w") as f:
+                f.write(sep.join(["chrom", "valid_coverage", "other", "percent_modified"]) + "\n")
+                for i in range(n):
+                    f.write(sep.join(["chr1", str(cov[i]), "x y", texts[i]]) + ("\r\n" if j == 1 else "\n"))
+            files.append(str(path))
+        got = tables.read_samples_native(files, sep == "\t")
+        want = _pandas_tables(files, sep == "\t")
+        assert got is not None
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # what the parser treats specially is left to pandas: NA in the coverage column, a quoted field
+    bad = tmp_path / "na.csv"
+    bad.write_text("valid_coverage,percent_modified\n3,0.5\nNA,0.25\n")
+    assert tables.read_samples_native([str(bad)], False) is None
+    quoted = tmp_path / "q.csv"
+    quoted.write_text('valid_coverage,percent_modified\n3,"0.5"\n')
+    assert tables.read_samples_native([str(quoted)], False) is None
+    # a single-column csv gets coverage 1 (demethify.py:137-138)
+    single = tmp_path / "single.csv"
+    single.write_text("percent_modified\n0.5\n0.125\n")
+    got = tables.read_samples_native([str(single)], False)
+    want = _pandas_tables([str(single)], False)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[1].tolist() == [[1], [1]]
