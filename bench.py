@@ -279,18 +279,26 @@ def main():
 
     if rank == 0:
         b_alg = algorithmic_bytes(N, S, n_c, n_u)
-        flops = algorithmic_flops(N, S, n_c, n_u)
         fam_ms = {k: (v[0] / max(v[1], 1), v[1]) for k, v in fam.items()}
-        # dominant kernel family of the outer iteration and its algorithmic traffic per launch.  With the fused
-        # row pass (--kernels 0) ONE launch of the "rowpass" family does the whole V / D stream of an outer
-        # iteration (1 unit = 1 outer iteration per launch): B_alg of SURVEY.md 8(d).  The unfused pair
-        # (--kernels 3) reads V and D once per kernel.
-        per_launch_bytes = {
-            "rowpass": N * S * 16 + N * 8 * (n_c + 3 * n_u),   # V, D, R_trunc, u, u_ in; u out
-            "gram": N * S * 16 + N * 8 * (n_c + n_u),          # V, D, R_trunc, u in (unfused levels only)
-        }
-        dom = max(("rowpass", "gram"), key=lambda k: fam[k][0])
         names = dict(tok.split("=", 1) for tok in kernels.split() if "=" in tok and tok.split("=")[0] in ("rowpass", "gram", "alpha"))
+        n_p = n_u * (n_u + 1) // 2
+        nd = 2 if "nd=2" in names.get("gram", "") else 1
+        # Algorithmic (compulsory) HBM bytes per launch of each streaming kernel, 1 unit = 1 outer iteration per launch.
+        # SURVEY.md 8(d) counts V and the counts at 8 bytes each (B_alg = 16 N S + 8 N (n_c + 3 n_u)); the second-
+        # generation kernels read the counts as u16 (row pass) and as 8-bit digit planes (integer Gram), an exact
+        # re-encoding, so THEIR compulsory bytes are what `achieved` is computed from -- pricing them at 16 bytes per
+        # element would report bytes that are never moved.
+        if names.get("rowpass", "").startswith("k_rowpass_v2"):
+            row_bytes = N * S * (8 + 2) + N * 8 * (n_c + 4 * n_u)       # V f64, counts u16, R_trunc, u + u_ in and out
+            gram_bytes = N * S * nd + N * 8 * (n_c + n_u)               # count digit planes, R_trunc, u
+            row_flop = N * S * (2 * n_c + 4 * n_u + 2 * n_p + 2) + T2 * N * (2 * n_u * n_u + 8 * n_u)
+        else:
+            row_bytes = N * S * 16 + N * 8 * (n_c + 4 * n_u)
+            gram_bytes = 0 if names.get("gram") == "fused" else N * S * 16 + N * 8 * (n_c + n_u)
+            row_flop = algorithmic_flops(N, S, n_c, n_u) if names.get("gram") == "fused" else \
+                N * S * (2 * n_c + 4 * n_u + 2 * n_p + 2) + T2 * N * (2 * n_u * n_u + 8 * n_u)
+        per_launch_bytes = {"rowpass": row_bytes, "gram": gram_bytes}
+        dom = max(("rowpass", "gram"), key=lambda k: fam[k][0])
         dom_kernel = names.get(dom, dom)
         if dom == "gram" and dom_kernel == "fused":
             dom_kernel = "k_gram_reduce"
@@ -310,6 +318,8 @@ def main():
                 traffic = None
         ms_per_step = elapsed / args.steps * 1e3
         loop_rate = iters_total / loop_s if loop_s > 0 else 0.0
+        iter_bytes = row_bytes + gram_bytes
+        gram_ms = fam_ms["gram"][0]
         out = {
             "metric": "NMF update iters/sec (1e6 CpG x 256 samples x 16 types)" if args.workload.startswith("headline")
                       else f"NMF update iters/sec ({args.workload})",
@@ -339,14 +349,20 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": per_launch_bytes[dom],
                 "avg_launch_ms": dom_ms,
-                # the same launch against the FP64 roof (SURVEY 8d flop count of the one-pass form; FP64 MFMA and
-                # FP64 VALU share one pipe on gfx950): whichever fraction is larger binds
-                "fp64": {"flop_per_launch": flops, "achieved": flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0,
+                # the same launch against the FP64 roof: flops the row pass executes in this formulation (FP64 MFMA and
+                # FP64 VALU share one pipe on gfx950)
+                "fp64": {"flop_per_launch": row_flop, "achieved": row_flop / (fam_ms["rowpass"][0] * 1e-3) / 1e12 if fam_ms["rowpass"][0] > 0 else 0.0,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / (dom_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if dom_ms > 0 else 0.0},
-                "whole_iteration": {"algorithmic_bytes": b_alg,
-                                    "achieved": b_alg * loop_rate / 1e9,
-                                    "frac": b_alg * loop_rate / 1e9 / HBM_PEAK_GBS},
+                         "frac": row_flop / (fam_ms["rowpass"][0] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if fam_ms["rowpass"][0] > 0 else 0.0},
+                # second kernel of the outer iteration (family "gram": the integer-matrix-core GEMM + its reduction)
+                "gram": {"kernel": names.get("gram"), "avg_ms": gram_ms, "algorithmic_bytes": gram_bytes,
+                         "achieved": gram_bytes / (gram_ms * 1e-3) / 1e9 if gram_ms > 0 else 0.0, "unit": "GB/s",
+                         "int8_ops": 2 * N * S * (n_c * n_u + n_p) * 7 * nd if "i8" in names.get("gram", "") else None},
+                "whole_iteration": {"algorithmic_bytes": iter_bytes, "achieved": iter_bytes * loop_rate / 1e9,
+                                    "frac": iter_bytes * loop_rate / 1e9 / HBM_PEAK_GBS,
+                                    # SURVEY 8(d)'s f64-layout figure (16 B per element) times the same rate: what the
+                                    # iteration would have to stream without the integer re-encoding; NOT bytes moved
+                                    "sec8d_f64_layout_bytes": b_alg, "sec8d_f64_layout_equivalent": b_alg * loop_rate / 1e9},
                 "family_avg_ms": {k: round(v[0], 4) for k, v in fam_ms.items()},
                 "family_launches": {k: v[1] for k, v in fam_ms.items()},
             },

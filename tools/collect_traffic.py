@@ -31,7 +31,7 @@ def main():
     fetch = per_kernel_mean(fetch_dir, "FETCH_SIZE")
     write = per_kernel_mean(write_dir, "WRITE_SIZE")
     table = json.loads(out_path.read_text()) if out_path.exists() else {}
-    entry = table.setdefault(workload, {})
+    entry = table[workload] = {}  # kernels of older commits do not linger
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
@@ -41,6 +41,11 @@ def main():
             "hbm_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0,
             "correction": "2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request) + WRITE_SIZE, KiB -> bytes",
         }
+    import subprocess
+
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                          cwd=Path(__file__).resolve().parent.parent).stdout.strip()
+    table["_commit"] = head or "unknown"  # bench.py quotes it next to roofline.traffic
     out_path.write_text(json.dumps(table, indent=1, sort_keys=True) + "\n")
     print(json.dumps(entry, indent=1))
 
