@@ -436,7 +436,7 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
         {
             FamilyScope scope(ctx, DMF_KERNEL_ROWPASS);
             HIP_TRY(dmf::launch_rowpass_v2(p->V, p->D16, p->SD, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, S,
-                                           n_c, n_u, n_iter2, s->mode, s->slab, s->u2_partials, &grid, ctx->stream));
+                                           n_c, n_u, n_iter2, s->mode, p->ND, s->slab, s->u2_partials, &grid, ctx->stream));
         }
         HIP_TRY(dmf::launch_finish_u_norm(s->u2_partials, grid, s->state, ctx->stream));
         {
@@ -775,6 +775,23 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
                 (reinterpret_cast<uintptr_t>(p->V) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0 &&
                 dmf::rowpass_v2_supported((int)S, (int)n_c, (int)n_u, 20) &&
                 dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
+    if (s->use_v2) {
+        // the row pass writes alpha_j alpha_l in fixed point on [0, 1]: true of every iterate (columns on the simplex),
+        // checked for the caller's starting point
+        std::vector<double> ha((size_t)K * S);
+        hipError_t ec = hipMemcpyAsync(ha.data(), alpha0, ha.size() * sizeof(double),
+                                       (flags & DMF_PTR_DEVICE) ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, ctx->stream);
+        if (ec == hipSuccess) ec = hipStreamSynchronize(ctx->stream);
+        if (ec != hipSuccess) {
+            delete s;
+            return hip_fail(ec, "copy alpha0", __LINE__);
+        }
+        for (double a : ha)
+            if (!(a >= 0.0 && a <= 1.0)) {
+                s->use_v2 = false;
+                break;
+            }
+    }
     s->use_fused = (ctx->generic_level == 0 || ctx->generic_level == 4) && p->d_f32_exact && N >= 16 &&
                    dmf::rowpass_fused_supported((int)S, (int)n_c, (int)n_u) &&
                    dmf::u_phase_mfma_supported((int)S, (int)n_c, (int)n_u) && dmf::gram_u_supported((int)n_c, (int)n_u);

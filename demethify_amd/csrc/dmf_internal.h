@@ -173,7 +173,7 @@ int rowpass_v2_grid(int64_t N, int S);
 // u phase + b_u slab ([grid][n_u][S] doubles) + per-workgroup ||u||^2 shares in one read of V (f64) and D16
 hipError_t launch_rowpass_v2(const double* V, const unsigned short* D16, int SD, const double* Rtp, const double* alpha,
                              double* u, double* u_prev, SolverState* state, int64_t N, int S, int n_c, int n_u,
-                             int n_iter2, int mode, double* slab, double* u2_partials, int* grid_out, hipStream_t st);
+                             int n_iter2, int mode, int nd, double* slab, double* u2_partials, int* grid_out, hipStream_t st);
 bool gram_i8_supported(int n_c, int n_u, int ND, int64_t N, int SD);
 int64_t gram_i8_slab_words(int64_t N, int SD, int n_c, int n_u);  // i64 words of the slab
 int64_t gram_i8_acc_words(int S, int n_c, int n_u);               // i64 words of the reduction scratch (zero-initialised)

@@ -14,7 +14,8 @@
 //   tile    prefetched global loads (V: 16 B per lane, two rows per instruction; D16: 16 B = 8 counts per lane)
 //           -> LDS tile of the wave's own column group (V f64, D as f32: exact for counts < 2^24)
 //   phase A FP64-MFMA contractions on the tile in the row-on-lane layout (as dmf_kernels_rowpass_mfma.hip):
-//           E = V - Rt a_known (16x16x4), c = a_unk (D*E)^T (4x4x4, 4 blocks), M = P D^T (16x16x4) -> partial c / M
+//           E = V - Rt a_known (16x16x4), c = a_unk (D*E)^T (4x4x4, 4 blocks); M = D P^T exactly on the i8 MFMA
+//           (16x16x64, counts and P = alpha_j alpha_l as balanced 8-bit digits) -> partial c / M
 //   -- barrier X --
 //   phase B (one wave, round robin) sums the partials and runs the n_iter2 accelerated projected-gradient steps,
 //           lane = (row, unknown); u / u_ go to HBM and u to LDS
@@ -23,10 +24,12 @@
 // Rows beyond N in the last block read a clamped V row and zero counts (D16 is zero-padded to a multiple of 16 rows
 // and of 64 columns), so they add nothing; their u is never stored.
 //
-// Preconditions (checked by the launcher): S even, S <= 256, n_c <= 16, n_u <= 4, counts integral and <= 65535.
+// Preconditions (checked by the launcher / the solver): S even, S <= 256, n_c <= 16, n_u <= 4, counts integral and
+// <= 32639 (nd = 1: <= 127), alpha within [0, 1] (true of every iterate: columns on the simplex).
 #include "dmf_device.h"
 #include "dmf_internal.h"
 #include "dmf_phaseb.h"
+#include "dmf_fixedpoint.h"
 #include <cstdlib>
 
 namespace dmf {
@@ -35,6 +38,8 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 // Diagnostic build only (tools/rowpass2_probe.hip defines DMF_STAMPS): per-wave cycle sums of the kernel's segments
 // go to a debug buffer of their own; the product build compiles none of it.
@@ -58,8 +63,10 @@ __device__ __forceinline__ unsigned long long dmf2_stamp() {
 namespace {
 constexpr int kRowV = 66;  // V tile row: 64 samples + 16 B pad (f64)
 constexpr int kRowD = 68;  // D tile row: 64 samples + 16 B pad (f32)
+constexpr int kRowB = 80;  // count-digit tile row: 64 samples (1 byte each) + 16 B pad
 constexpr int kTileVBytes2 = 16 * kRowV * 8;
-constexpr int kTileBytes2 = kTileVBytes2 + 16 * kRowD * 4;  // one column group
+constexpr int kTileDBytes2 = 16 * kRowD * 4;
+constexpr int kTileBytes2 = kTileVBytes2 + kTileDBytes2 + 2 * 16 * kRowB;  // one column group: V, D (f32), 2 digit planes
 }  // namespace
 
 // One accelerated projected-gradient step of a row group (deconvolution.py:83-88): (cur, prev) = (u, u_) in,
@@ -96,7 +103,7 @@ template <int NKC, int NU>
 __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
     const double* __restrict__ V, const unsigned short* __restrict__ D16, int SD, const double* __restrict__ Rtp,
     const double* __restrict__ alpha, double* __restrict__ u, double* __restrict__ u_prev,
-    const SolverState* __restrict__ state, int64_t N, int S, int n_c, int n_iter2, int mode,
+    const SolverState* __restrict__ state, int64_t N, int S, int n_c, int n_iter2, int mode, int nd,
     double* __restrict__ slab, double* __restrict__ u2_partials
 #ifdef DMF_STAMPS
     , unsigned long long* __restrict__ stamps_out
@@ -123,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
     char* __restrict__ tile = reinterpret_cast<char*>(u2red + 4) + (size_t)wave * kTileBytes2;
     double* __restrict__ tileV = reinterpret_cast<double*>(tile);
     float* __restrict__ tileD = reinterpret_cast<float*>(tile + kTileVBytes2);
+    char* __restrict__ tileB = tile + kTileVBytes2 + kTileDBytes2;  // [2 digit planes][16][kRowB]: counts as balanced bytes
 
     if (threadIdx.x == 0) {
         double a1 = state->a1, lw_prev = state->l_w_prev;
@@ -141,7 +149,12 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
     const int k_col = wcol0 + 4 * q;                        // + 16 t + r: k-step r, k = q <-> sample
     double a1r[4][NKC > 0 ? NKC : 1];  // -alpha_known[k = 4 kc + q][sample]
     double a2r[4][4];                  // alpha_unk[m16 & 3][sample] (c product, 4x4x4: block = 4 rows, i = unknown)
-    double ppr[4][4];                  // alpha_unk[j] * alpha_unk[l] of pair p = m16 (M product)
+    // M product (M_i[pair] = sum_s alpha_j alpha_l d_is) on the INTEGER matrix cores, exactly: the counts are one or two
+    // balanced 8-bit digits, P = alpha_j alpha_l in [0, 1] seven digits of rint(P 2^52) (dmf_fixedpoint.h), one
+    // v_mfma_i32_16x16x64_i8 per digit covers the wave's 64 samples (A = count digits [row][sample], B = digit t of
+    // P [sample][pair]).  An FP64 MFMA holds the SIMD's FP64 pipe for 64 cycles, and this product was 16 of the 28 per
+    // block and wave -- time during which the other workgroup's phases B and C on the same SIMD could not issue.
+    v4i pdg[7];  // B operands: digit t of P[pair = m16][samples 16 q .. 16 q + 15 of this column group]
     {
         int pj = 0, pl = 0;
         while ((pl + 1) * (pl + 2) / 2 <= m16) ++pl;
@@ -158,10 +171,29 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int col = k_col + 16 * t + r;
-                const bool in = col < S;
-                a2r[t][r] = (in && a2_ok) ? alpha[(int64_t)(n_c + (m16 & 3)) * S + col] : 0.0;
-                ppr[t][r] = (in && pair_ok) ? alpha[(int64_t)(n_c + pj) * S + col] * alpha[(int64_t)(n_c + pl) * S + col] : 0.0;
+                a2r[t][r] = (col < S && a2_ok) ? alpha[(int64_t)(n_c + (m16 & 3)) * S + col] : 0.0;
             }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // four samples per dword of each digit
+            unsigned int lo[4], hi[4], tl[4], th[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = wcol0 + 16 * q + 4 * g + i;
+                const bool in = pair_ok && col < S;
+                const double aj = in ? alpha[(int64_t)(n_c + pj) * S + col] : 0.0;
+                const double al = in ? alpha[(int64_t)(n_c + pl) * S + col] : 0.0;
+                z_to_biased(aj, al, lo[i], hi[i]);
+            }
+            transpose4(lo, tl);
+            transpose4(hi, th);
+            pdg[0][g] = (int)(tl[0] ^ 0x80808080u);
+            pdg[1][g] = (int)(tl[1] ^ 0x80808080u);
+            pdg[2][g] = (int)(tl[2] ^ 0x80808080u);
+            pdg[3][g] = (int)(tl[3] ^ 0x80808080u);
+            pdg[4][g] = (int)(th[0] ^ 0x80808080u);
+            pdg[5][g] = (int)(th[1] ^ 0x80808080u);
+            pdg[6][g] = (int)th[2];
         }
     }
     __syncthreads();  // beta_tab
@@ -236,6 +268,13 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
             const v4u w = pd[i];
             *reinterpret_cast<v4f*>(dst) = v4f{(float)(w.x & 0xFFFFu), (float)(w.x >> 16), (float)(w.y & 0xFFFFu), (float)(w.y >> 16)};
             *reinterpret_cast<v4f*>(dst + 4) = v4f{(float)(w.z & 0xFFFFu), (float)(w.z >> 16), (float)(w.w & 0xFFFFu), (float)(w.w >> 16)};
+            // the same counts as balanced digits: d + 128 = b0 + 256 b1, digit 0 = b0 - 128 (b0 ^ 0x80 as i8), digit 1 = b1
+            const unsigned int e0 = w.x + 0x00800080u, e1 = w.y + 0x00800080u, e2 = w.z + 0x00800080u, e3 = w.w + 0x00800080u;
+            char* __restrict__ bdst = tileB + (8 * i + d_row) * kRowB + d_col;
+            *reinterpret_cast<v2u*>(bdst) = v2u{__builtin_amdgcn_perm(e1, e0, 0x06040200u) ^ 0x80808080u,
+                                                __builtin_amdgcn_perm(e3, e2, 0x06040200u) ^ 0x80808080u};
+            *reinterpret_cast<v2u*>(bdst + 16 * kRowB) = v2u{__builtin_amdgcn_perm(e1, e0, 0x07050301u),
+                                                             __builtin_amdgcn_perm(e3, e2, 0x07050301u)};
         }
         double rtop[NKC > 0 ? NKC : 1];
 #pragma unroll
@@ -264,10 +303,9 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
             R.df = *reinterpret_cast<const v4f*>(tileD + m16 * kRowD + t * 16 + 4 * q);
         };
         double csm0 = 0.0, csm1 = 0.0;  // c[unknown q][row m16], one double per lane
-        v4d macc = {0.0, 0.0, 0.0, 0.0}, macc1 = macc;
         auto e_init = [&](const Strip& R) { return v4d{R.v01.x, R.v01.y, R.v23.x, R.v23.y}; };
         auto run_strip = [&](const Strip& R, v4d e, const Strip& Rn, const double (&a1n)[NKC > 0 ? NKC : 1],
-                             const double (&a2)[4], const double (&pp)[4], bool has_next) {
+                             const double (&a2)[4], bool has_next) {
             const v4d d = {(double)R.df.x, (double)R.df.y, (double)R.df.z, (double)R.df.w};
             const v4d w = d * e;
             v4d en = e_init(Rn);
@@ -275,8 +313,6 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
             for (int r = 0; r < 4; ++r) {
                 if (r & 1) csm1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[r], w[r], csm1, 0, 0, 0);
                 else csm0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[r], w[r], csm0, 0, 0, 0);
-                if (r & 1) macc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pp[r], d[r], macc1, 0, 0, 0);
-                else macc = __builtin_amdgcn_mfma_f64_16x16x4f64(pp[r], d[r], macc, 0, 0, 0);
                 if (has_next && r < NKC) en = __builtin_amdgcn_mfma_f64_16x16x4f64(a1n[r], rtop[r], en, 0, 0, 0);
             }
             return en;
@@ -288,16 +324,38 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
         v4d e0 = e_init(sa);
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) e0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1r[0][kc], rtop[kc], e0, 0, 0, 0);
-        const v4d e1 = run_strip(sa, e0, sb, a1r[1], a2r[0], ppr[0], true);
+        const v4d e1 = run_strip(sa, e0, sb, a1r[1], a2r[0], true);
         load_strip(2, sa);
         __builtin_amdgcn_sched_barrier(0);
-        const v4d e2 = run_strip(sb, e1, sa, a1r[2], a2r[1], ppr[1], true);
+        const v4d e2 = run_strip(sb, e1, sa, a1r[2], a2r[1], true);
         load_strip(3, sb);
         __builtin_amdgcn_sched_barrier(0);
-        const v4d e3 = run_strip(sa, e2, sb, a1r[3], a2r[2], ppr[2], true);
-        (void)run_strip(sb, e3, sb, a1r[3], a2r[3], ppr[3], false);
-        macc += macc1;
+        const v4d e3 = run_strip(sa, e2, sb, a1r[3], a2r[2], true);
+        (void)run_strip(sb, e3, sb, a1r[3], a2r[3], false);
         const double csm = csm0 + csm1;
+        // M on the integer matrix cores: digit weights 256^0 .. 256^7 (count digit d + P digit t -> weight t + d)
+        v4i mw[8];
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) mw[w8] = v4i{0, 0, 0, 0};
+        {
+            const v4i c0 = *reinterpret_cast<const v4i*>(tileB + m16 * kRowB + 16 * q);  // A: counts [row m16][16 samples]
+#pragma unroll
+            for (int t = 0; t < 7; ++t) mw[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(c0, pdg[t], mw[t], 0, 0, 0);
+            if (nd == 2) {
+                const v4i c1 = *reinterpret_cast<const v4i*>(tileB + (16 + m16) * kRowB + 16 * q);
+#pragma unroll
+                for (int t = 0; t < 7; ++t) mw[t + 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(c1, pdg[t], mw[t + 1], 0, 0, 0);
+            }
+        }
+        // lane (pair m16, q) holds rows 4 q + reg: the exact integer sum_w 256^w mw[w] in two halves that fit a double
+        // without rounding (|mw| < 2^21 per digit product sum), one rounding when they are joined
+        double mrow[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const double lo = fma(fma(fma((double)mw[3][rr], 256.0, (double)mw[2][rr]), 256.0, (double)mw[1][rr]), 256.0, (double)mw[0][rr]);
+            const double hi = fma(fma(fma((double)mw[7][rr], 256.0, (double)mw[6][rr]), 256.0, (double)mw[5][rr]), 256.0, (double)mw[4][rr]);
+            mrow[rr] = fma(hi, 0x1p32, lo) * 0x1p-52;
+        }
         DMF2_STAMP(1)  // phase A
         // the next block's global loads: their staging registers were free during phase A, and the loads have
         // phases B and C (and the other workgroups' turns on this CU) to land
@@ -305,10 +363,9 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
         {
             double* __restrict__ mine = red + (size_t)wave * NV * 16;
             if (q < NU) mine[q * 16 + m16] = csm;  // c[unknown q][row m16]
+            if (m16 < NP) {  // C layout of the 16x16x64 tile: col = pair m16, rows 4 q + reg
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int p = q + 4 * rr;  // C layout of the 16x16x4 tile: row (= pair) q + 4 reg, col = m16
-                if (p < NP) mine[(NU + p) * 16 + m16] = macc[rr];
+                for (int rr = 0; rr < 4; ++rr) mine[(NU + m16) * 16 + 4 * q + rr] = mrow[rr];
             }
         }
         DMF2_STAMP(2)  // prefetch issue + partials
@@ -424,7 +481,7 @@ size_t rowpass_v2_lds_bytes(int S, int n_u, int n_iter2) {
 
 bool rowpass_v2_supported(int S, int n_c, int n_u, int n_iter2) {
     if ((S & 1) != 0 || S < 2 || S > 256 || n_c > 16 || n_u < 1 || n_u > 4) return false;
-    return rowpass_v2_lds_bytes(S, n_u, n_iter2) <= 64 * 1024;
+    return rowpass_v2_lds_bytes(S, n_u, n_iter2) <= 80 * 1024;  // two workgroups per CU within 160 KB
 }
 
 int rowpass_v2_grid(int64_t N, int S) {
@@ -439,23 +496,23 @@ int rowpass_v2_grid(int64_t N, int S) {
 template <int NKC, int NU>
 static hipError_t launch_v2_t(const double* V, const unsigned short* D16, int SD, const double* Rtp, const double* alpha,
                               double* u, double* u_prev, SolverState* state, int64_t N, int S, int n_c, int n_iter2,
-                              int mode, double* slab, double* u2_partials, int* grid_out, hipStream_t st) {
+                              int mode, int nd, double* slab, double* u2_partials, int* grid_out, hipStream_t st) {
     const int NW = (S + 63) / 64;
     const size_t lds = rowpass_v2_lds_bytes(S, NU, n_iter2);
-    if (lds > 64 * 1024 || N < 1 || SD < NW * 64 || (SD & 7) != 0) return hipErrorInvalidValue;
+    if (lds > 80 * 1024 || N < 1 || SD < NW * 64 || (SD & 7) != 0 || nd < 1 || nd > 2) return hipErrorInvalidValue;
     static bool lds_limit_raised[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (lds > 48 * 1024 && !lds_limit_raised[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)k_rowpass_v2<NKC, NU>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           64 * 1024);
+                                           80 * 1024);
         if (e != hipSuccess) return e;
         lds_limit_raised[dev] = true;
     }
     const int grid = rowpass_v2_grid(N, S);
     *grid_out = grid;
     hipLaunchKernelGGL((k_rowpass_v2<NKC, NU>), dim3(grid), dim3(NW * 64), lds, st, V, D16, SD, Rtp, alpha, u, u_prev,
-                       state, N, S, n_c, n_iter2, mode, slab, u2_partials
+                       state, N, S, n_c, n_iter2, mode, nd, slab, u2_partials
 #ifdef DMF_STAMPS
                        , (unsigned long long*)nullptr
 #endif
@@ -466,12 +523,12 @@ static hipError_t launch_v2_t(const double* V, const unsigned short* D16, int SD
 template <int NKC>
 static hipError_t launch_v2_nkc(int n_u, const double* V, const unsigned short* D16, int SD, const double* Rtp,
                                 const double* alpha, double* u, double* u_prev, SolverState* state, int64_t N, int S,
-                                int n_c, int n_iter2, int mode, double* slab, double* u2_partials, int* grid_out,
+                                int n_c, int n_iter2, int mode, int nd, double* slab, double* u2_partials, int* grid_out,
                                 hipStream_t st) {
     switch (n_u) {
 #define DMF_CASE(NU_)                                                                                            \
     case NU_:                                                                                                    \
-        return launch_v2_t<NKC, NU_>(V, D16, SD, Rtp, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, slab, \
+        return launch_v2_t<NKC, NU_>(V, D16, SD, Rtp, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, nd, slab, \
                                      u2_partials, grid_out, st);
         DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4)
 #undef DMF_CASE
@@ -481,11 +538,11 @@ static hipError_t launch_v2_nkc(int n_u, const double* V, const unsigned short* 
 
 hipError_t launch_rowpass_v2(const double* V, const unsigned short* D16, int SD, const double* Rtp, const double* alpha,
                              double* u, double* u_prev, SolverState* state, int64_t N, int S, int n_c, int n_u,
-                             int n_iter2, int mode, double* slab, double* u2_partials, int* grid_out, hipStream_t st) {
+                             int n_iter2, int mode, int nd, double* slab, double* u2_partials, int* grid_out, hipStream_t st) {
     switch ((n_c + 3) / 4) {
 #define DMF_NKC(X)                                                                                                \
     case X:                                                                                                       \
-        return launch_v2_nkc<X>(n_u, V, D16, SD, Rtp, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, slab, \
+        return launch_v2_nkc<X>(n_u, V, D16, SD, Rtp, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, nd, slab, \
                                 u2_partials, grid_out, st);
         DMF_NKC(0) DMF_NKC(1) DMF_NKC(2) DMF_NKC(3) DMF_NKC(4)
 #undef DMF_NKC

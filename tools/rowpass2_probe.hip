@@ -26,11 +26,11 @@ int main(int argc, char** argv) {
     SolverState h{}; h.a1 = 1; h.a2 = 1; h.l_w = 1e4; h.l_w_prev = 1e4; h.l_h = 1e6; h.l_h_prev = 1e6; h.dsq = 6400;
     hipMemcpy(st, &h, sizeof(h), hipMemcpyHostToDevice); hipMemset(stamps, 0, (size_t)grid * 4 * 8 * 8);
     const size_t lds = rowpass_v2_lds_bytes(S, n_u, T2);
-    hipFuncSetAttribute((const void*)k_rowpass_v2<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    hipFuncSetAttribute((const void*)k_rowpass_v2<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_rowpass_v2<3, 4>), dim3(grid), dim3(256), lds, 0, V, D, 256, R, a, u, up, st, N, S, n_c, T2, 0, slab, u2, stamps);
+        hipLaunchKernelGGL((k_rowpass_v2<3, 4>), dim3(grid), dim3(256), lds, 0, V, D, 256, R, a, u, up, st, N, S, n_c, T2, 0, 1, slab, u2, stamps);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); printf("launch %d: %.3f ms  (%s)\n", rep, ms, hipGetErrorString(hipGetLastError()));
     }
