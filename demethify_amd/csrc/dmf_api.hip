@@ -93,6 +93,7 @@ struct dmf_solver {
     int64_t beta_cap = 0;  // shapes beyond the lane-per-sample kernel's registers: MFMA Gram
     bool use_fused = false;      // first-generation fused row pass (counts as f64 in HBM, FP64 Gram in the kernel)
     bool use_v2 = false;         // second generation: u16 counts in the row pass + integer-MFMA Gram
+    bool use_gram_i8 = false;    // u phase as a kernel of its own (n_u > 4 ...), Gram on the integer matrix cores + k_bu_cols
     long long* slab_i8 = nullptr;   // i64 partial sums of the integer Gram (one slab per row range)
     long long* acc_i8 = nullptr;    // reduction scratch of the integer Gram (kept zero between iterations)
     double* purity = nullptr;  // S per-sample known-block masses: set => Frank-Wolfe alpha phase
@@ -377,10 +378,22 @@ int enqueue_u_phase(dmf_solver* s, int n_iter2) {
     return DMF_OK;
 }
 
-int enqueue_gram(dmf_solver* s) {
+int enqueue_gram(dmf_solver* s, bool after_u_phase = false) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
     FamilyScope scope(ctx, DMF_KERNEL_GRAM);
+    if (s->use_gram_i8 && after_u_phase) {
+        // (only behind a u phase: its clip puts u inside [0, 1], which the fixed-point features need; the
+        // dmf_update_alpha entry point hands over the caller's u and stays on the FP64 kernels)
+        const int S = (int)p->S, n_c = (int)p->n_c, n_u = (int)s->n_u, nf = n_c * n_u + n_u * (n_u + 1) / 2;
+        int n_slabs = 0, ny = 0;
+        HIP_TRY(dmf::launch_bu_cols(p->V, p->D16, p->SD, s->u, p->N, S, n_u, s->slab, &s->state->done, &n_slabs, ctx->stream));
+        HIP_TRY(dmf::launch_gram_i8(p->Dt8, p->plane_stride, p->SD, p->ND, p->Rtp, s->u, p->N, n_c, n_u, s->job_k, s->job_l, nf,
+                                    s->slab_i8, &s->state->done, &ny, ctx->stream));
+        HIP_TRY(dmf::launch_gram_v2_reduce(s->slab_i8, ny, nf, p->SD, s->slab, n_slabs, n_u, S, s->acc_i8, s->job_dst, s->gb,
+                                           &s->state->done, ctx->stream));
+        return DMF_OK;
+    }
     if (s->use_gram_spec) {
         int ny = 0;
         HIP_TRY(dmf::launch_gram_u(p->V, p->D, p->Rtp, s->u, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, s->slab,
@@ -485,7 +498,7 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
     HIP_TRY(dmf::launch_sumsq_f64(s->u, p->N * s->n_u, ctx->scratch, &s->state->u_norm2, &s->state->done,
                                   ctx->stream));
     HIP_TRY(dmf::launch_set_lh(s->state, ctx->stream));
-    DMF_TRY(enqueue_gram(s));
+    DMF_TRY(enqueue_gram(s, true));
     DMF_TRY(enqueue_alpha_phase(s, n_iter2));
     return DMF_OK;
 }
@@ -775,6 +788,15 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
                 (reinterpret_cast<uintptr_t>(p->V) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0 &&
                 dmf::rowpass_v2_supported((int)S, (int)n_c, (int)n_u, 20) &&
                 dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
+    // shapes the second-generation row pass does not take (n_u 5..20, long inner loops): the u phase stays a kernel of its
+    // own, the Gram pass becomes the integer GEMM + the b_u stream kernel (V f64 + u16 counts instead of V and D f64
+    // and n_u (n_u + 3) / 2 + n_c n_u FP64 FMAs per element)
+    // Measured at 5e5 x 128 (tools/gram_i8_vs_fp64.py): 6+6 (57 features) 0.25 against 0.35 ms for k_gram_u, but 0+5 / 0+8 /
+    // 0+12 0.25 / 0.25 / 0.34 against 0.19 / 0.22 / 0.31 ms -- without known types the FP64 Gram is cheap and the four
+    // launches of this route are not; so: only with known types and at least 40 features.
+    s->use_gram_i8 = ctx->generic_level == 0 && p->ND > 0 && p->D16 != nullptr && n_c > 0 && p->Rtp != nullptr &&
+                     n_c * n_u + n_u * (n_u + 1) / 2 >= 40 && n_u <= 20 && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0 &&
+                     dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
     if (s->use_v2) {
         // the row pass writes alpha_j alpha_l in fixed point on [0, 1]: true of every iterate (columns on the simplex),
         // checked for the caller's starting point
@@ -829,6 +851,10 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
         const int64_t bu = (int64_t)dmf::rowpass_v2_grid(N, (int)S) * n_u * S;
         if (bu > s->slab_doubles) s->slab_doubles = bu;
     }
+    if (s->use_gram_i8) {
+        const int64_t bu = (int64_t)dmf::bu_cols_grid(N) * n_u * S;
+        if (bu > s->slab_doubles) s->slab_doubles = bu;
+    }
     const size_t un = (size_t)N * n_u * sizeof(double), an = (size_t)K * S * sizeof(double);
     const size_t un_alloc = (un + 15) & ~(size_t)15;  // the integer Gram kernel fetches u in 16-byte pieces
     const size_t gbn = (size_t)(K + 1) * (K + 2) / 2 * S * sizeof(double);
@@ -842,9 +868,9 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->slab, (size_t)s->slab_doubles * sizeof(double));
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->partials, (size_t)2 * (nb_alpha + S) * sizeof(double));
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->u2_partials, 4096 * sizeof(double));
-    if (e == hipSuccess && s->use_v2)
+    if (e == hipSuccess && (s->use_v2 || s->use_gram_i8))
         e = pool_alloc(ctx, (void**)&s->slab_i8, (size_t)dmf::gram_i8_slab_words(N, p->SD, (int)n_c, (int)n_u) * sizeof(long long));
-    if (e == hipSuccess && s->use_v2) {
+    if (e == hipSuccess && (s->use_v2 || s->use_gram_i8)) {
         const size_t bytes = (size_t)dmf::gram_i8_acc_words((int)S, (int)n_c, (int)n_u) * sizeof(long long);
         e = pool_alloc(ctx, (void**)&s->acc_i8, bytes);
         if (e == hipSuccess) e = hipMemsetAsync(s->acc_i8, 0, bytes, ctx->stream);
@@ -994,7 +1020,8 @@ int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t
         else if (s->u_path == 0) snprintf(row, sizeof(row), "k_u_phase_mfma");
         else if (s->u_path == 1) snprintf(row, sizeof(row), "k_u_phase_gram");
         else snprintf(row, sizeof(row), "k_u_step_direct");
-        snprintf(gram, sizeof(gram), "%s", s->use_gram_spec ? "k_gram_u" : s->use_gram_mfma ? "k_gram_mfma" : "k_gram");
+        if (s->use_gram_i8) snprintf(gram, sizeof(gram), "k_bu_cols+k_gram_i8<nd=%d>", p->ND);
+        else snprintf(gram, sizeof(gram), "%s", s->use_gram_spec ? "k_gram_u" : s->use_gram_mfma ? "k_gram_mfma" : "k_gram");
     }
     const bool tps = s->ctx->generic_level == 1 || s->ctx->generic_level == 2;
     const char* alpha = s->purity != nullptr ? (K <= 16 && n_c >= 1 ? "k_alpha_frank_wolfe_row16" : "k_alpha_frank_wolfe")

@@ -183,6 +183,10 @@ int64_t gram_i8_acc_words(int S, int n_c, int n_u);               // i64 words o
 hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, int ND, const double* Rtp, const double* u,
                           int64_t N, int n_c, int n_u, const short* feat_a, const short* feat_b, int NF, long long* slab,
                           const int* done_flag, int* ny_out, hipStream_t st);
+// b_u alone (for u phases that are kernels of their own): slab [n_slabs][n_u][S] doubles, n_u <= 20
+int bu_cols_grid(int64_t N);
+hipError_t launch_bu_cols(const double* V, const unsigned short* D16, int SD, const double* u, int64_t N, int S, int n_u,
+                          double* slab, const int* done_flag, int* n_slabs_out, hipStream_t st);
 // gb rows of the u-dependent jobs from the i64 slab (jobs < NF) and the row pass's b_u slabs (jobs NF .. NF + n_u);
 // acc_words: gram_i8_acc_words() i64 words, all zero before the first call (the kernels leave them zero again)
 hipError_t launch_gram_v2_reduce(const long long* slab_i8, int ny, int NF, int SD, const double* slab_bu, int n_bu_slabs,

@@ -300,6 +300,77 @@ __global__ __launch_bounds__(256) void k_gram_i8(const signed char* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ b_u alone
+// b_u[j][s] = sum_i u_ij d_is v_is for the solver paths whose u phase is a kernel of its own (n_u 5..20: the integer
+// GEMM above then takes all the V-free Gram entries and this stream kernel the one right-hand side that needs V).
+// Lane = sample, a row's u values are wave-uniform scalar loads, eight rows of V / D16 in flight per wave; the four
+// waves of a workgroup are summed in fixed order into one slab [NU][S] per workgroup.  HBM-bound: V (f64) + counts (u16).
+template <int NU>
+__global__ __launch_bounds__(256) void k_bu_cols(const double* __restrict__ V, const unsigned short* __restrict__ D16, int SD,
+                                                 const double* __restrict__ u, int64_t N, int S, double* __restrict__ slab,
+                                                 const int* __restrict__ done_flag) {
+    constexpr int kRows = 8;
+    __shared__ double red[3][NU][64];
+    if (done_flag != nullptr && *done_flag) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int s = blockIdx.y * 64 + lane;
+    const bool active = s < S;
+    const int sc = active ? s : S - 1;
+    double acc[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) acc[j] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t i0 = (int64_t)blockIdx.x * 4 + wave; i0 < N; i0 += kRows * stride) {
+        double t[kRows];
+        int64_t row[kRows];
+#pragma unroll
+        for (int x = 0; x < kRows; ++x) {
+            const int64_t i = i0 + x * stride;
+            row[x] = i < N ? i : N - 1;
+            const double d = i < N ? (double)D16[row[x] * SD + sc] : 0.0;
+            t[x] = d * V[row[x] * S + sc];
+        }
+#pragma unroll
+        for (int x = 0; x < kRows; ++x) {
+            const double* __restrict__ u_row = u + row[x] * NU;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) acc[j] = fma(t[x], u_row[j], acc[j]);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) red[wave - 1][j][lane] = acc[j];
+    }
+    __syncthreads();
+    if (wave == 0 && active) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j)
+            slab[((int64_t)blockIdx.x * NU + j) * S + s] = ((acc[j] + red[0][j][lane]) + red[1][j][lane]) + red[2][j][lane];
+    }
+}
+
+int bu_cols_grid(int64_t N) {
+    int64_t want = (N + 4 * 8 - 1) / (4 * 8);
+    if (want > 512) want = 512;
+    return (int)(want < 1 ? 1 : want);
+}
+
+hipError_t launch_bu_cols(const double* V, const unsigned short* D16, int SD, const double* u, int64_t N, int S, int n_u,
+                          double* slab, const int* done_flag, int* n_slabs_out, hipStream_t st) {
+    const int nbx = bu_cols_grid(N);
+    *n_slabs_out = nbx;
+    const dim3 grid(nbx, (S + 63) / 64), block(256);
+    switch (n_u) {
+#define DMF_CASE(NU_) \
+    case NU_: hipLaunchKernelGGL((k_bu_cols<NU_>), grid, block, 0, st, V, D16, SD, u, N, S, slab, done_flag); break;
+        DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4) DMF_CASE(5) DMF_CASE(6) DMF_CASE(7) DMF_CASE(8) DMF_CASE(9) DMF_CASE(10)
+        DMF_CASE(11) DMF_CASE(12) DMF_CASE(13) DMF_CASE(14) DMF_CASE(15) DMF_CASE(16) DMF_CASE(17) DMF_CASE(18) DMF_CASE(19) DMF_CASE(20)
+#undef DMF_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ reduce
 // Stage 1 (grid: sample blocks x jobs x kRedChunks): jobs < n_feat add their chunk of the i64 slabs into
 // acc64[half][job][S] with 64-bit integer atomics (exact, so the order of the adds cannot matter); jobs >= n_feat
