@@ -95,6 +95,7 @@ struct dmf_solver {
     bool use_v2 = false;         // second generation: u16 counts in the row pass + integer-MFMA Gram
     bool use_gram_i8 = false;    // u phase as a kernel of its own (n_u > 4 ...), Gram on the integer matrix cores + k_bu_cols
     long long* slab_i8 = nullptr;   // i64 partial sums of the integer Gram (one slab per row range)
+    int64_t slab_i8_words = 0;
     long long* acc_i8 = nullptr;    // reduction scratch of the integer Gram (kept zero between iterations)
     double* purity = nullptr;  // S per-sample known-block masses: set => Frank-Wolfe alpha phase
     double* u2_partials = nullptr;
@@ -389,7 +390,7 @@ int enqueue_gram(dmf_solver* s, bool after_u_phase = false) {
         int n_slabs = 0, ny = 0;
         HIP_TRY(dmf::launch_bu_cols(p->V, p->D16, p->SD, s->u, p->N, S, n_u, s->slab, &s->state->done, &n_slabs, ctx->stream));
         HIP_TRY(dmf::launch_gram_i8(p->Dt8, p->plane_stride, p->SD, p->ND, p->Rtp, s->u, p->N, n_c, n_u, s->job_k, s->job_l, nf,
-                                    s->slab_i8, &s->state->done, &ny, ctx->stream));
+                                    s->slab_i8, s->slab_i8_words, &s->state->done, &ny, ctx->stream));
         HIP_TRY(dmf::launch_gram_v2_reduce(s->slab_i8, ny, nf, p->SD, s->slab, n_slabs, n_u, S, s->acc_i8, s->job_dst, s->gb,
                                            &s->state->done, ctx->stream));
         return DMF_OK;
@@ -455,7 +456,7 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
         {
             FamilyScope scope(ctx, DMF_KERNEL_GRAM);
             HIP_TRY(dmf::launch_gram_i8(p->Dt8, p->plane_stride, p->SD, p->ND, p->Rtp, s->u, p->N, n_c, n_u, s->job_k,
-                                        s->job_l, nf, s->slab_i8, &s->state->done, &ny, ctx->stream));
+                                        s->job_l, nf, s->slab_i8, s->slab_i8_words, &s->state->done, &ny, ctx->stream));
             HIP_TRY(dmf::launch_gram_v2_reduce(s->slab_i8, ny, nf, p->SD, s->slab, grid, n_u, S, s->acc_i8, s->job_dst,
                                                s->gb, &s->state->done, ctx->stream));
         }
@@ -868,8 +869,10 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->slab, (size_t)s->slab_doubles * sizeof(double));
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->partials, (size_t)2 * (nb_alpha + S) * sizeof(double));
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->u2_partials, 4096 * sizeof(double));
-    if (e == hipSuccess && (s->use_v2 || s->use_gram_i8))
-        e = pool_alloc(ctx, (void**)&s->slab_i8, (size_t)dmf::gram_i8_slab_words(N, p->SD, (int)n_c, (int)n_u) * sizeof(long long));
+    if (e == hipSuccess && (s->use_v2 || s->use_gram_i8)) {
+        s->slab_i8_words = dmf::gram_i8_slab_words(N, p->SD, (int)n_c, (int)n_u);
+        e = pool_alloc(ctx, (void**)&s->slab_i8, (size_t)s->slab_i8_words * sizeof(long long));
+    }
     if (e == hipSuccess && (s->use_v2 || s->use_gram_i8)) {
         const size_t bytes = (size_t)dmf::gram_i8_acc_words((int)S, (int)n_c, (int)n_u) * sizeof(long long);
         e = pool_alloc(ctx, (void**)&s->acc_i8, bytes);

@@ -182,7 +182,7 @@ int64_t gram_i8_acc_words(int S, int n_c, int n_u);               // i64 words o
 // multiple of 16 bytes
 hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, int ND, const double* Rtp, const double* u,
                           int64_t N, int n_c, int n_u, const short* feat_a, const short* feat_b, int NF, long long* slab,
-                          const int* done_flag, int* ny_out, hipStream_t st);
+                          int64_t slab_words, const int* done_flag, int* ny_out, hipStream_t st);
 // b_u alone (for u phases that are kernels of their own): slab [n_slabs][n_u][S] doubles, n_u <= 20
 int bu_cols_grid(int64_t N);
 hipError_t launch_bu_cols(const double* V, const unsigned short* D16, int SD, const double* u, int64_t N, int S, int n_u,

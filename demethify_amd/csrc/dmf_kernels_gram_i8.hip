@@ -509,12 +509,14 @@ static hipError_t launch_gram_i8_t(const signed char* Dt8, int64_t plane_stride,
 
 hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, int ND, const double* Rtp, const double* u,
                           int64_t N, int n_c, int n_u, const short* fa, const short* fb, int NF, long long* slab,
-                          const int* done_flag, int* ny_out, hipStream_t st) {
+                          int64_t slab_words, const int* done_flag, int* ny_out, hipStream_t st) {
     int nsh, ny;
     int64_t rpw;
     gram_i8_geometry(N, SD, &nsh, &ny, &rpw);
     *ny_out = ny;
     const int MFtot = (NF + 31) / 32 * 32;
+    // every workgroup (row range) writes its own [2][MFtot][SD] slab: the buffer must hold all of them
+    if ((int64_t)ny * 2 * MFtot * SD > slab_words || rpw * 128 * 128 * ND >= (int64_t)1 << 31) return hipErrorInvalidValue;
     // accumulator registers: (7 + ND - 1) * NFT tiles of 16 per wave -> 64 features per launch with one count digit,
     // 32 with two; more features = more launches over the (small) 8-bit planes
     const int chunk = ND == 1 ? 64 : 32;
