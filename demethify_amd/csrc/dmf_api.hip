@@ -392,7 +392,7 @@ int enqueue_gram(dmf_solver* s, bool after_u_phase = false) {
         HIP_TRY(dmf::launch_gram_i8(p->Dt8, p->plane_stride, p->SD, p->ND, p->Rtp, s->u, p->N, n_c, n_u, s->job_k, s->job_l, nf,
                                     s->slab_i8, s->slab_i8_words, &s->state->done, &ny, ctx->stream));
         HIP_TRY(dmf::launch_gram_v2_reduce(s->slab_i8, ny, nf, p->SD, s->slab, n_slabs, n_u, S, s->acc_i8, s->job_dst, s->gb,
-                                           &s->state->done, ctx->stream));
+                                           &s->state->done, nullptr, 0, s->state, ctx->stream));
         return DMF_OK;
     }
     if (s->use_gram_spec) {
@@ -452,13 +452,12 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
             HIP_TRY(dmf::launch_rowpass_v2(p->V, p->D16, p->SD, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, S,
                                            n_c, n_u, n_iter2, s->mode, p->ND, s->slab, s->u2_partials, &grid, ctx->stream));
         }
-        HIP_TRY(dmf::launch_finish_u_norm(s->u2_partials, grid, s->state, ctx->stream));
         {
             FamilyScope scope(ctx, DMF_KERNEL_GRAM);
             HIP_TRY(dmf::launch_gram_i8(p->Dt8, p->plane_stride, p->SD, p->ND, p->Rtp, s->u, p->N, n_c, n_u, s->job_k,
                                         s->job_l, nf, s->slab_i8, s->slab_i8_words, &s->state->done, &ny, ctx->stream));
             HIP_TRY(dmf::launch_gram_v2_reduce(s->slab_i8, ny, nf, p->SD, s->slab, grid, n_u, S, s->acc_i8, s->job_dst,
-                                               s->gb, &s->state->done, ctx->stream));
+                                               s->gb, &s->state->done, s->u2_partials, grid, s->state, ctx->stream));
         }
         DMF_TRY(enqueue_alpha_phase(s, n_iter2));
         return DMF_OK;

@@ -188,10 +188,11 @@ int bu_cols_grid(int64_t N);
 hipError_t launch_bu_cols(const double* V, const unsigned short* D16, int SD, const double* u, int64_t N, int S, int n_u,
                           double* slab, const int* done_flag, int* n_slabs_out, hipStream_t st);
 // gb rows of the u-dependent jobs from the i64 slab (jobs < NF) and the row pass's b_u slabs (jobs NF .. NF + n_u);
-// acc_words: gram_i8_acc_words() i64 words, all zero before the first call (the kernels leave them zero again)
+// acc_words: gram_i8_acc_words() i64 words, all zero before the first call (the kernels leave them zero again);
+// u2_partials != null: the finish kernel also sums the row pass's ||u||^2 shares into state (u_norm2, l_h)
 hipError_t launch_gram_v2_reduce(const long long* slab_i8, int ny, int NF, int SD, const double* slab_bu, int n_bu_slabs,
                                  int n_u, int S, long long* acc_words, const int* dst_row, double* gb, const int* done_flag,
-                                 hipStream_t st);
+                                 const double* u2_partials, int n_u2, SolverState* state, hipStream_t st);
 
 // two percentiles over axis 0 of x[n][m] -> out0[m], out1[m] (out1 may be null); dmf_kernels_percentile.hip
 hipError_t launch_percentile_pair(const double* x, int64_t n, int64_t m, PercentilePlan p0, PercentilePlan p1,

@@ -426,8 +426,21 @@ __global__ __launch_bounds__(256) void k_gram_v2_reduce(const long long* __restr
 
 __global__ __launch_bounds__(64) void k_gram_v2_finish(unsigned long long* __restrict__ acc64, const double* __restrict__ bu_part,
                                                        int n_u, int n_feat, int S, const int* __restrict__ dst_row,
-                                                       double* __restrict__ gb, const int* __restrict__ done_flag) {
+                                                       double* __restrict__ gb, const int* __restrict__ done_flag,
+                                                       const double* __restrict__ u2_partials, int n_u2,
+                                                       SolverState* __restrict__ state) {
     if (done_flag != nullptr && *done_flag) return;
+    if (u2_partials != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
+        // the row pass's per-workgroup shares of ||u||_F^2 -> state->u_norm2 and l_h (deconvolution.py:212), summed in
+        // workgroup order: one launch less per outer iteration than a kernel of its own
+        double a = 0.0;
+        for (int i = threadIdx.x; i < n_u2; i += 64) a += u2_partials[i];
+        a = wave_sum(a);
+        if (threadIdx.x == 0) {
+            state->u_norm2 = a;
+            state->l_h = (state->rt_norm2 + a) * state->dsq;
+        }
+    }
     const int s = blockIdx.x * 64 + threadIdx.x;
     const int job = blockIdx.y;
     if (s >= S) return;
@@ -537,14 +550,14 @@ hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, 
 
 hipError_t launch_gram_v2_reduce(const long long* slab_i8, int ny, int NF, int SD, const double* slab_bu, int n_bu_slabs,
                                  int n_u, int S, long long* acc_words, const int* dst_row, double* gb, const int* done_flag,
-                                 hipStream_t st) {
+                                 const double* u2_partials, int n_u2, SolverState* state, hipStream_t st) {
     const int MF = (NF + 31) / 32 * 32;
     unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(acc_words);
     double* bu_part = reinterpret_cast<double*>(acc_words + (int64_t)2 * NF * S);
     hipLaunchKernelGGL(k_gram_v2_reduce, dim3((S + 63) / 64, NF + n_u, kRedChunks), dim3(256), 0, st, slab_i8, ny, MF, SD,
                        slab_bu, n_bu_slabs, n_u, NF, S, acc64, bu_part, done_flag);
     hipLaunchKernelGGL(k_gram_v2_finish, dim3((S + 63) / 64, NF + n_u), dim3(64), 0, st, acc64, bu_part, n_u, NF, S, dst_row,
-                       gb, done_flag);
+                       gb, done_flag, u2_partials, n_u2, state);
     return hipGetLastError();
 }
 
