@@ -12,10 +12,10 @@ namespace dmf {
 // (0 <= a_6 <= 17).
 __device__ __forceinline__ void z_to_biased(double xa, double xb, unsigned int& lo, unsigned int& hi) {
     const double y = fma(xa, xb, 1.0);
-    const unsigned int l = (unsigned int)__double2loint(y);
-    const unsigned int l2 = l + 0x80808080u;
-    lo = l2;
-    hi = (unsigned int)__double2hiint(y) - 0x3FF00000u + 0x00008080u + (l2 < l ? 1u : 0u);
+    // one 64-bit add: bits(y) - bits(1.0) + bias
+    const unsigned long long s = (unsigned long long)__double_as_longlong(y) + (0x0000808080808080ull - 0x3FF0000000000000ull);
+    lo = (unsigned int)s;
+    hi = (unsigned int)(s >> 32);
 }
 
 // 4 x 4 byte transpose: digits t = 0..3 of four 32-bit words w[0..3] (byte t of word r -> byte r of out[t])

@@ -300,6 +300,261 @@ __global__ __launch_bounds__(256) void k_gram_i8(const signed char* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the GEMM, 8 waves
+// Diagnostic build only (tools/gram_i8_probe.hip defines DMF_STAMPS): per-wave cycle sums of the block loop's segments.
+#ifdef DMF_STAMPS
+#define DMFG_STAMP_DECL unsigned long long st_last = dmfg_stamp(), st_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DMFG_STAMP(i) { const unsigned long long st_now = dmfg_stamp(); st_seg[i] += st_now - st_last; st_last = st_now; }
+#define DMFG_STAMP_FLUSH if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) stamps_out[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + i_] = st_seg[i_];
+__device__ __forceinline__ unsigned long long dmfg_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#else
+#define DMFG_STAMP_DECL
+#define DMFG_STAMP(i)
+#define DMFG_STAMP_FLUSH
+#endif
+
+// The headline shapes (one count digit, 33..64 features): the same product on EIGHT waves, two per SIMD.  In-kernel
+// stamps of the four-wave kernel above showed its 2.0 k cycles per 32-row block to be one wave's serial instruction
+// stream -- DMA issue 0.35 k, LDS round trips 0.5 k + 0.4 k, digit arithmetic 0.6 k, 14 MFMAs 0.45 k of matrix pipe --
+// and reordering that stream (operands preloaded a block ahead, MFMAs interleaved with the digit arithmetic) moved
+// nothing: with 480 registers there is one wave per SIMD and nobody to issue while it waits.  Here a wave keeps ONE
+// feature half (32 features x 32 samples x 7 digits = 112 accumulator registers), wave = (sample group w & 3, feature
+// half w >> 2), so that two waves share a SIMD and each other's LDS / DMA / barrier waits:
+//   * DMA per block: waves 0..3 fetch the count tile of their sample group, waves 4..7 the XL pieces of the x image;
+//   * digits: wave w converts rows 4 w .. 4 w + 3 of all 64 features (lane = feature), one dword per digit;
+//   * three A tiles: iteration b multiplies block b from operands read at the end of iteration b - 1, converts block
+//     b + 2 and reads the operands of block b + 1.
+template <int XL>
+__global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restrict__ Dt8, int64_t plane_stride, int SB,
+                                                    const double* __restrict__ Rtp, int nct, const double* __restrict__ u,
+                                                    int64_t N, int n_c, int n_u, const short* __restrict__ feat_a,
+                                                    const short* __restrict__ feat_b, int NF, int p0, int MFtot,
+                                                    int64_t rows_per_wg, long long* __restrict__ slab, int SDs,
+                                                    const int* __restrict__ done_flag
+#ifdef DMF_STAMPS
+                                                    , unsigned long long* __restrict__ stamps_out
+#endif
+                                                    ) {
+    constexpr int MF = 64, MA = kNSL * MF;  // feature slots per digit (lane = feature), rows of the A tile
+    constexpr int kSlotB = 4 * 1024, kSlotX = XL * 4096, kSlot = kSlotB + kSlotX;
+    constexpr int kAtile = 2 * MA * 4;  // dwords of one block's A tile [2 (h)][MA][4]
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    char* __restrict__ ring = lds_raw;                                                            // [kRing][kSlot]
+    unsigned int* __restrict__ atile = reinterpret_cast<unsigned int*>(lds_raw + kRing * kSlot);  // [3][2 (h)][MA][4]
+    if (done_flag != nullptr && *done_flag) return;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int sg = wave & 3, fh = wave >> 2;
+    const int sb = blockIdx.x * 4 + sg;  // this wave's block of 32 samples
+    const bool wave_on = sb < SB;
+    const int sbc = wave_on ? sb : SB - 1;
+    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_wg;  // multiple of 32
+    int64_t r_end = r_begin + rows_per_wg;
+    if (r_end > N) r_end = N;
+    const int nb = r_end > r_begin ? (int)((r_end - r_begin + 31) / 32) : 0;
+    if (nb == 0) return;
+
+    for (int i = tid; i < 3 * kAtile; i += 512) atile[i] = 0u;
+
+    // this lane's feature: byte offsets of its two factors inside a block's x image
+    // [R_trunc rows: 32 x nct doubles (the padded copy)][u rows: 32 x n_u doubles]
+    // digit conversion: wave w = features 16 (w & 3) .. + 15 x rows 16 (w >> 2) .. + 15, lane = (feature l & 15, row
+    // quad l >> 4): a lane's four rows are one dword of the A tile, and a 32-lane group (16 features x 2 quads) writes
+    // banks 4 f + q -- two-way, which a ds_write_b32 hides -- and reads rows 4 apart (conflict-free: 96-B rows)
+    const int feat = 16 * (wave & 3) + (lane & 15), quad = lane >> 4, row_first = 16 * (wave >> 2) + 4 * quad;
+    const bool feat_on = feat < NF;
+    int offA = 0, strideA = 0, offB = 0, strideB = 0;
+    if (feat_on) {
+        const int ia = feat_a[p0 + feat], ib = feat_b[p0 + feat];
+        offA = ia < n_c ? ia * 8 : 256 * nct + (ia - n_c) * 8;
+        strideA = ia < n_c ? nct * 8 : n_u * 8;
+        offB = ib < n_c ? ib * 8 : 256 * nct + (ib - n_c) * 8;
+        strideB = ib < n_c ? nct * 8 : n_u * 8;
+    }
+    offA += row_first * strideA;
+    offB += row_first * strideB;
+
+    v16i acc[kNSL];
+#pragma unroll
+    for (int a = 0; a < kNSL; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][e] = 0;
+
+    // One DMA descriptor per lane and piece: source = base + min(block * step, limit).  Waves 0..3 fetch the count tile
+    // of their sample group (one piece), waves 4..7 the XL pieces of the x image: 16-B chunk c of
+    // [32 rows of the padded R_trunc copy][32 rows of u]; the limit keeps the last block's chunks inside the arrays
+    // (rows of the padded copy are multiples of 32 B; u may end on an odd double, the solver rounds its allocation up).
+    const char* gbase[XL];
+    int64_t glim[XL];
+    int gstep[XL], lds_dst[XL];
+#pragma unroll
+    for (int x = 0; x < XL; ++x) {
+        if (wave < 4) {
+            gbase[x] = reinterpret_cast<const char*>(Dt8) + (((r_begin >> 5) * SB + sbc) * 1024 + (lane & 31) * 32 + (lane >> 5) * 16);
+            gstep[x] = SB * 1024;
+            glim[x] = (int64_t)1 << 62;
+            lds_dst[x] = sg * 1024;
+        } else {
+            const int n_chunk_rt = 16 * nct, n_chunks = 16 * (nct + n_u);
+            int c = (tid - 256) + 256 * x;
+            if (c >= n_chunks) c = n_chunks - 1;  // lands in the slot's padding
+            if (c < n_chunk_rt) {
+                const int64_t off0 = r_begin * nct * 8 + (int64_t)c * 16;
+                gbase[x] = reinterpret_cast<const char*>(Rtp) + off0;
+                gstep[x] = 32 * nct * 8;
+                glim[x] = N * nct * 8 - 16 - off0;
+            } else {
+                const int64_t off0 = r_begin * n_u * 8 + (int64_t)(c - n_chunk_rt) * 16;
+                gbase[x] = reinterpret_cast<const char*>(u) + off0;
+                gstep[x] = 32 * n_u * 8;
+                glim[x] = ((N * n_u * 8 - 8) & ~(int64_t)15) - off0;
+            }
+            lds_dst[x] = kSlotB + (x * 4 + (wave - 4)) * 1024;
+        }
+    }
+    const bool tail_clamp = r_end == N && (N & 31) != 0;  // only the last block of the last row range can run past N
+    auto issue = [&](int j) {
+        const int jc = j < nb ? j : nb - 1;  // beyond the range: a repeat of the last block keeps the DMA count uniform
+        char* __restrict__ slot = ring + (j % kRing) * kSlot;
+#pragma unroll
+        for (int x = 0; x < XL; ++x) {
+            if (x > 0 && wave < 4) break;
+            int64_t off = (int64_t)jc * gstep[x];
+            if (tail_clamp && jc == nb - 1) off = off < glim[x] ? off : glim[x];
+            __builtin_amdgcn_global_load_lds((gmem_void*)(gbase[x] + off), (lds_int*)(slot + lds_dst[x]), 16, 0, 0);
+        }
+    };
+    // rows of block j's two factors (this lane's feature, its four rows) into registers
+    double xa[4], xv[4];
+    auto read_rows = [&](int j) {
+        const char* __restrict__ xb = ring + (j % kRing) * kSlot + kSlotB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xa[r] = *reinterpret_cast<const double*>(xb + offA + r * strideA);  // (offset 0 without a feature)
+            xv[r] = *reinterpret_cast<const double*>(xb + offB + r * strideB);
+        }
+    };
+    // ... and from there, as seven digit dwords, into A tile `buf`
+    unsigned int lo[4], hi[4], tl[4], th[4];
+    // (lanes without a feature convert whatever row 0 / column 0 holds: their digits land in A-tile rows whose
+    // accumulators are never stored -- no select)
+    auto convert_row = [&](int r) { z_to_biased(xa[r], xv[r], lo[r], hi[r]); };
+    auto store_digits = [&](int buf) {
+        unsigned int* __restrict__ at = atile + buf * kAtile + (((wave >> 2) * MA + feat) << 2) + quad;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) at[(t * MF) << 2] = tl[t] ^ 0x80808080u;
+        at[(4 * MF) << 2] = th[0] ^ 0x80808080u;
+        at[(5 * MF) << 2] = th[1] ^ 0x80808080u;
+        at[(6 * MF) << 2] = th[2];
+    };
+    auto generate = [&](int buf) {  // (prologue: the whole conversion in one piece)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) convert_row(r);
+        transpose4(lo, tl);
+        transpose4(hi, th);
+        store_digits(buf);
+    };
+    v4i bq, aop[kNSL];
+    auto load_operands = [&](int j, int abuf) {
+        bq = *reinterpret_cast<const v4i*>(ring + (j % kRing) * kSlot + sg * 1024 + lane * 16);
+        const unsigned int* __restrict__ at = atile + abuf * kAtile + (((lane >> 5) * MA + 32 * fh + (lane & 31)) << 2);
+#pragma unroll
+        for (int t = 0; t < kNSL; ++t) aop[t] = *reinterpret_cast<const v4i*>(at + ((t * MF) << 2));
+    };
+
+    // prologue: kRing - 1 blocks in flight; digits of blocks 0 and 1; operands of block 0; rows of block 2
+#pragma unroll 1
+    for (int j = 0; j < kRing - 1; ++j) issue(j);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_rows(0);
+    generate(0);
+    read_rows(nb > 1 ? 1 : 0);
+    generate(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load_operands(0, 0);
+    read_rows(nb > 2 ? 2 : nb - 1);
+
+    DMFG_STAMP_DECL
+    int a_cur = 0;  // A tile of block b (b % 3 without the division)
+#pragma unroll 1
+    for (int b = 0; b < nb; ++b) {
+        const int a_next = a_cur == 2 ? 0 : a_cur + 1, a_gen = a_next == 2 ? 0 : a_next + 1;
+        issue(b + kRing - 1);  // into the slot of block b - 1: its count tile and its rows went to registers long ago
+        DMFG_STAMP(0)
+        // own DMA of blocks <= b + 3 landed, own LDS traffic (digit writes, operand and row reads) done; then everyone's
+        // (waves 0..3 have one DMA per block in flight, waves 4..7 XL)
+        if (XL == 1 || wave < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kRing - 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kRing - 4) * XL) : "memory");
+        DMFG_STAMP(1)
+        __builtin_amdgcn_s_barrier();
+        DMFG_STAMP(2)
+        // Block b's seven MFMAs (operands in registers since the end of the last iteration), one per piece of the
+        // conversion of block b + 2 (rows in registers likewise), in this order and no other: an MFMA holds the matrix
+        // pipe for 32 cycles, a piece is 7-10 vector instructions.  No branches: a wave beyond the last sample block
+        // multiplies a repeat tile into accumulators that are never stored, lanes without a feature produce the
+        // all-zero digits of z = 0.
+        // Each register is refilled from LDS as soon as its consumer has issued -- A operand t of block b + 1 behind
+        // MFMA t, row r of block b + 3 behind its conversion, the count tile behind the last MFMA -- so that the LDS
+        // array works during the matrix phase and only the seven digit stores remain behind it.
+        const int j_op = b + 1 < nb ? b + 1 : b, j_row = b + 3 < nb ? b + 3 : nb - 1;
+        const unsigned int* __restrict__ at_next = atile + a_next * kAtile + (((lane >> 5) * MA + 32 * fh + (lane & 31)) << 2);
+        const char* __restrict__ xb_next = ring + (j_row % kRing) * kSlot + kSlotB;
+#pragma unroll
+        for (int t = 0; t < kNSL; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[t], bq, acc[t], 0, 0, 0);
+            if (t < 4) convert_row(t);
+            else if (t == 4) transpose4(lo, tl);
+            else if (t == 5) transpose4(hi, th);
+            __builtin_amdgcn_sched_barrier(0);
+            aop[t] = *reinterpret_cast<const v4i*>(at_next + ((t * MF) << 2));
+            if (t < 4) {
+                xa[t] = *reinterpret_cast<const double*>(xb_next + offA + t * strideA);
+                xv[t] = *reinterpret_cast<const double*>(xb_next + offB + t * strideB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bq = *reinterpret_cast<const v4i*>(ring + (j_op % kRing) * kSlot + sg * 1024 + lane * 16);
+        DMFG_STAMP(3)
+        store_digits(a_gen);
+        a_cur = a_next;
+        DMFG_STAMP(4)
+    }
+    DMFG_STAMP_FLUSH
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (repeat) DMAs must not outlive the workgroup's LDS
+
+    // slab[y][half][feature slot][sample] (i64), as the four-wave kernel writes it
+    if (wave_on) {
+        const int n = lane & 31, h = lane >> 5;
+        long long* __restrict__ out = slab + ((int64_t)blockIdx.y * 2 * MFtot + p0) * SDs + sb * 32 + n;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int p = 32 * fh + m;
+            long long lo = 0, hi = 0;
+#pragma unroll
+            for (int wt = 0; wt < kNSL; ++wt) {
+                const long long v = (long long)acc[wt][e];
+                if (wt < 4) lo += v << (8 * wt);
+                else hi += v << (8 * (wt - 4));
+            }
+            if (p < NF) {
+                out[(int64_t)p * SDs] = lo;
+                out[(int64_t)(MFtot + p) * SDs] = hi;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ b_u alone
 // b_u[j][s] = sum_i u_ij d_is v_is for the solver paths whose u phase is a kernel of its own (n_u 5..20: the integer
 // GEMM above then takes all the V-free Gram entries and this stream kernel the one right-hand side that needs V).
@@ -498,6 +753,33 @@ size_t gram_i8_lds_bytes(int nft, int nd, int xl) {
     return (size_t)kRing * (4 * nd * 1024 + xl * 4096) + (size_t)2 * 2 * (kNSL * 32 * nft) * 16;
 }
 
+size_t gram_i8_w8_lds_bytes(int xl) { return (size_t)kRing * (4096 + xl * 4096) + (size_t)3 * 2 * (kNSL * 64) * 16; }
+
+template <int XL>
+static hipError_t launch_gram_i8_w8_t(const signed char* Dt8, int64_t plane_stride, int SD, const double* Rtp, const double* u,
+                                      int64_t N, int n_c, int n_u, const short* fa, const short* fb, int NF, int p0, int MFtot,
+                                      long long* slab, const int* done_flag, hipStream_t st) {
+    int nsh, ny;
+    int64_t rpw;
+    gram_i8_geometry(N, SD, &nsh, &ny, &rpw);
+    const size_t lds = gram_i8_w8_lds_bytes(XL);
+    static bool lds_limit_raised[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!lds_limit_raised[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gram_i8_w8<XL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_limit_raised[dev] = true;
+    }
+    hipLaunchKernelGGL((k_gram_i8_w8<XL>), dim3(nsh, ny), dim3(512), lds, st, Dt8, plane_stride, SD / 32, Rtp,
+                       (n_c + 3) / 4 * 4, u, N, n_c, n_u, fa, fb, NF, p0, MFtot, rpw, slab, SD, done_flag
+#ifdef DMF_STAMPS
+                       , (unsigned long long*)nullptr
+#endif
+                       );
+    return hipGetLastError();
+}
+
 template <int NFT, int ND, int XL>
 static hipError_t launch_gram_i8_t(const signed char* Dt8, int64_t plane_stride, int SD, const double* Rtp, const double* u,
                                    int64_t N, int n_c, int n_u, const short* fa, const short* fb, int NF, int p0, int MFtot,
@@ -539,7 +821,10 @@ hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, 
 #define DMF_GI8(F, D_, X)                                                                                                 \
     e = launch_gram_i8_t<F, D_, X>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st)
         const bool wide = (n_c + 3) / 4 * 4 + n_u > 16;  // x image of a block beyond 4 KB: two DMA pieces per thread
-        if (ND == 1 && nf > 32) { if (wide) DMF_GI8(2, 1, 2); else DMF_GI8(2, 1, 1); }
+        if (ND == 1 && nf > 32) {  // the headline shapes: eight waves, two per SIMD
+            if (wide) e = launch_gram_i8_w8_t<2>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
+            else e = launch_gram_i8_w8_t<1>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
+        }
         else if (ND == 1) { if (wide) DMF_GI8(1, 1, 2); else DMF_GI8(1, 1, 1); }
         else { if (wide) DMF_GI8(1, 2, 2); else DMF_GI8(1, 2, 1); }
 #undef DMF_GI8
