@@ -24,10 +24,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
-import queue
 import subprocess
 import sys
-import threading
 import time
 from pathlib import Path
 
@@ -88,17 +86,12 @@ def restart_init(k, N, S, n_c, n_u):
     return u0, np.ascontiguousarray(a0)
 
 
-class InitFeeder(threading.Thread):
-    """Draws the (u0, alpha0) of this rank's restarts one ahead of the GPU (numpy's generators release the GIL)."""
+def restart_init_on_device(k, shape, ctx):
+    """The restart's initialisation drawn on the host and uploaded through page-locked memory on the context's copy stream
+    (demethify_amd/staging.py, dmf_stage_upload) -- by a worker thread, while the GPU iterates the restart before it."""
+    from demethify_amd import staging
 
-    def __init__(self, ks, shape):
-        super().__init__(daemon=True)
-        self.ks, self.shape = ks, shape
-        self.q = queue.Queue(maxsize=2)
-
-    def run(self):
-        for k in self.ks:
-            self.q.put((k, restart_init(k, *self.shape)))
+    return staging.to_device(restart_init(k, *shape), ctx)
 
 
 def cpu_baseline(V_dev, D_dev, Rt_dev, n_u, N_full, rows=(250_000, 1_000_000)):
@@ -190,7 +183,7 @@ def main():
             dist.init_process_group(backend="gloo")
 
     from demethify_amd import _lib as L
-    from demethify_amd import shard
+    from demethify_amd import shard, staging
     from demethify_amd.device import Context, Problem, Solver
 
     N, S, n_c, n_u = WORKLOADS[args.workload]
@@ -205,7 +198,9 @@ def main():
 
     # ---- warm-up: W untimed steps of one restart per rank (+ the collectives once, so that RCCL's lazy
     # communicator set-up is not in the timed region)
-    u0, a0 = restart_init(rank, N, S, n_c, n_u)
+    # (the warm-up restart goes through the staging path too: page-locked buffers and the copy stream exist afterwards)
+    staging.reserve(((N, n_u), (K, S)), count=2)
+    u0, a0 = staging.to_device(restart_init(rank, N, S, n_c, n_u), ctx)
     with Solver(problem, u0, a0, L.DMF_MODE_PARTIAL) as s:
         kernels = s.describe(T2)
         s.step(args.warmup, T2, 0.0)
@@ -225,11 +220,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     # ------------------------------------------------------------------ timed region: the restart job
-    feeder = InitFeeder(mine, (N, S, n_c, n_u))
-    feeder.start()
+    feeder = staging.Prefetcher(mine, lambda k: restart_init_on_device(k, (N, S, n_c, n_u), ctx), depth=2, workers=2)
     best, local_costs, loop_s, iters_total = None, {}, 0.0, 0
-    for _ in mine:
-        k, (u0, a0) = feeder.q.get()
+    for k, (u0, a0) in feeder:
         s = Solver(problem, u0, a0, L.DMF_MODE_PARTIAL)
         tl = time.perf_counter()
         it, _ = s.step(args.steps, T2, 0.0)  # returns after the last iteration's state has been read back
@@ -337,7 +330,7 @@ def main():
             "config": {"workload": args.workload, "N_cpg": N, "S_samples": S, "n_known": n_c, "n_unknown": n_u,
                        "inner_iters": T2, "restarts": R, "restart_seed": "1 + k", "restart_placement": "k mod n_gpus",
                        "unit_of_work": "one step = one outer iteration (20 u + 20 alpha inner updates + cost) of each "
-                                       "of the R restarts; timed: host init + upload + set-up + K iterations + "
+                                       "of the R restarts; timed: host init + upload (a worker thread, one restart ahead) + set-up + K iterations + "
                                        "cost_f_w per restart, one all-reduce(min), winner broadcast",
                        "parallelism": f"restart-sharded x{world}", "kernels": kernels,
                        "best_restart": int(best_k), "best_restart_cost": float(costs[best_k]), "head": git_head()},

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <vector>
 
 #include "../../include/demethify_hip.h"
@@ -56,6 +57,8 @@ struct dmf_context {
                             // 3 separate MFMA row pass + one-pass Gram (the pieces the fused kernel is made of)
     double* scratch = nullptr;  // 4096 doubles of reduction scratch
     hipMemPool_t pool = nullptr;  // the context's own stream-ordered pool (the device's default pool is not touched)
+    hipStream_t copy_stream = nullptr;  // dmf_stage_upload: uploads beside the kernels of `stream` (created on first use)
+    std::mutex copy_mutex;
     FamilyClock clocks[DMF_KERNEL_FAMILIES];
 };
 
@@ -603,9 +606,42 @@ int dmf_context_destroy(dmf_context* ctx) {
         for (auto ev : c.stop) hipEventDestroy(ev);
     }
     hipFree(ctx->scratch);
+    if (ctx->copy_stream != nullptr) {
+        hipStreamSynchronize(ctx->copy_stream);
+        hipStreamDestroy(ctx->copy_stream);
+    }
     if (ctx->pool != nullptr) (void)hipMemPoolDestroy(ctx->pool);  // hands the cached buffers back to the driver
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
+    return DMF_OK;
+}
+
+/* Staging for a restart loop (demethify/demethify.py:165-171,195-201): the next restart's initialisation goes to the
+ * device from a worker thread, on a copy stream of the context's own, while `stream` runs the current restart; the
+ * solver is then created from the device copy (DMF_PTR_DEVICE).  Thread-safe; returns when the copy is complete. */
+int dmf_stage_upload(dmf_context* ctx, const void* host, size_t bytes, void** out_dev) {
+    if (ctx == nullptr || host == nullptr || out_dev == nullptr || bytes == 0) return DMF_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));  // (the current device is per thread)
+    std::lock_guard<std::mutex> lock(ctx->copy_mutex);
+    if (ctx->copy_stream == nullptr) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    void* d = nullptr;
+    if (pool_enabled() && ctx->pool != nullptr) HIP_TRY(hipMallocFromPoolAsync(&d, bytes, ctx->pool, ctx->copy_stream));
+    else HIP_TRY(hipMalloc(&d, bytes));
+    hipError_t e = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx->copy_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return hip_fail(e, "dmf_stage_upload", __LINE__);
+    }
+    *out_dev = d;
+    return DMF_OK;
+}
+
+int dmf_stage_free(dmf_context* ctx, void* dev) {
+    if (ctx == nullptr) return DMF_ERR_BAD_ARG;
+    if (dev == nullptr) return DMF_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    pool_free(ctx, dev);  // ordered behind the work of `stream` that read it
     return DMF_OK;
 }
 

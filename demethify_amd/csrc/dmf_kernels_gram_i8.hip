@@ -353,10 +353,23 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int sg = wave & 3, fh = wave >> 2;
-    const int sb = blockIdx.x * 4 + sg;  // this wave's block of 32 samples
+    // Workgroups of one row range (they fetch the same rows of R_trunc and u) onto ONE XCD, so that the second fetch
+    // finds the rows in that XCD's L2: consecutive workgroup ids go round the 8 XCDs, hence range y = 8 k + xcd and
+    // sample quarter x take id = 8 (k nsh + x) + xcd.  (1-D launch; any other grid shape keeps the natural order.)
+    const int nsh = (SB + 3) / 4, n_wg = (int)gridDim.x, ny = n_wg / nsh;
+    int bx, by;
+    if (ny % 8 == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        bx = slot % nsh;
+        by = (slot / nsh) * 8 + xcd;
+    } else {
+        bx = blockIdx.x % nsh;
+        by = blockIdx.x / nsh;
+    }
+    const int sb = bx * 4 + sg;  // this wave's block of 32 samples
     const bool wave_on = sb < SB;
     const int sbc = wave_on ? sb : SB - 1;
-    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_wg;  // multiple of 32
+    const int64_t r_begin = (int64_t)by * rows_per_wg;  // multiple of 32
     int64_t r_end = r_begin + rows_per_wg;
     if (r_end > N) r_end = N;
     const int nb = r_end > r_begin ? (int)((r_end - r_begin + 31) / 32) : 0;
@@ -486,48 +499,75 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
 
     DMFG_STAMP_DECL
     int a_cur = 0;  // A tile of block b (b % 3 without the division)
+    // The block loop, unrolled over the ring: slot numbers are then constants and every LDS address of the body is a
+    // loop-invariant register plus an immediate (the issue slots of the SIMD, ~4 cycles per vector or LDS instruction
+    // of either wave, are what bounds this kernel -- stamps: the matrix phase takes 2 x (instructions) x 4 cycles).
+    // Reads for blocks beyond the range (rows of b + 3, operands of b + 1) go to whatever the slot holds: their
+    // registers are never consumed.
+    const char* __restrict__ rowA = ring + kSlotB + offA;
+    const char* __restrict__ rowB = ring + kSlotB + offB;
+    const char* __restrict__ bsrc = ring + sg * 1024 + lane * 16;
 #pragma unroll 1
-    for (int b = 0; b < nb; ++b) {
-        const int a_next = a_cur == 2 ? 0 : a_cur + 1, a_gen = a_next == 2 ? 0 : a_next + 1;
-        issue(b + kRing - 1);  // into the slot of block b - 1: its count tile and its rows went to registers long ago
-        DMFG_STAMP(0)
-        // own DMA of blocks <= b + 3 landed, own LDS traffic (digit writes, operand and row reads) done; then everyone's
-        // (waves 0..3 have one DMA per block in flight, waves 4..7 XL)
-        if (XL == 1 || wave < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kRing - 4) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kRing - 4) * XL) : "memory");
-        DMFG_STAMP(1)
-        __builtin_amdgcn_s_barrier();
-        DMFG_STAMP(2)
-        // Block b's seven MFMAs (operands in registers since the end of the last iteration), one per piece of the
-        // conversion of block b + 2 (rows in registers likewise), in this order and no other: an MFMA holds the matrix
-        // pipe for 32 cycles, a piece is 7-10 vector instructions.  No branches: a wave beyond the last sample block
-        // multiplies a repeat tile into accumulators that are never stored, lanes without a feature produce the
-        // all-zero digits of z = 0.
-        // Each register is refilled from LDS as soon as its consumer has issued -- A operand t of block b + 1 behind
-        // MFMA t, row r of block b + 3 behind its conversion, the count tile behind the last MFMA -- so that the LDS
-        // array works during the matrix phase and only the seven digit stores remain behind it.
-        const int j_op = b + 1 < nb ? b + 1 : b, j_row = b + 3 < nb ? b + 3 : nb - 1;
-        const unsigned int* __restrict__ at_next = atile + a_next * kAtile + (((lane >> 5) * MA + 32 * fh + (lane & 31)) << 2);
-        const char* __restrict__ xb_next = ring + (j_row % kRing) * kSlot + kSlotB;
+    for (int b0 = 0; b0 < nb; b0 += kRing) {
 #pragma unroll
-        for (int t = 0; t < kNSL; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[t], bq, acc[t], 0, 0, 0);
-            if (t < 4) convert_row(t);
-            else if (t == 4) transpose4(lo, tl);
-            else if (t == 5) transpose4(hi, th);
-            __builtin_amdgcn_sched_barrier(0);
-            aop[t] = *reinterpret_cast<const v4i*>(at_next + ((t * MF) << 2));
-            if (t < 4) {
-                xa[t] = *reinterpret_cast<const double*>(xb_next + offA + t * strideA);
-                xv[t] = *reinterpret_cast<const double*>(xb_next + offB + t * strideB);
+        for (int uu = 0; uu < kRing; ++uu) {
+            const int b = b0 + uu;
+            if (b >= nb) break;
+            constexpr int kMask = kRing - 1;
+            const int a_next = a_cur == 2 ? 0 : a_cur + 1, a_gen = a_next == 2 ? 0 : a_next + 1;
+            DMFG_STAMP(0)
+            // own DMA of blocks <= b + 3 landed, own LDS traffic (digit writes, operand and row reads) done; then
+            // everyone's (waves 0..3 have one DMA per block in flight, waves 4..7 XL)
+            // (the DMA of block b + kRing - 1 is issued further down, in the matrix phase: blocks b + 4 .. b + kRing - 2
+            // may still be in flight here)
+            if (XL == 1 || wave < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kRing - 5) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kRing - 5) * XL) : "memory");
+            DMFG_STAMP(1)
+            __builtin_amdgcn_s_barrier();
+            DMFG_STAMP(2)
+            // Block b's seven MFMAs (operands in registers since the last iteration), one per piece of the conversion of
+            // block b + 2 (rows in registers likewise), in this order and no other.  Each register is refilled from LDS
+            // as soon as its consumer has issued -- A operand t of block b + 1 behind MFMA t, row r of block b + 3
+            // behind its conversion, the count tile behind the last MFMA -- so that the LDS array works during the
+            // matrix phase and only the seven digit stores remain behind it.  No branches: a wave beyond the last
+            // sample block multiplies a repeat tile into accumulators that are never stored.
+            const unsigned int* __restrict__ at_next = atile + a_next * kAtile + (((lane >> 5) * MA + 32 * fh + (lane & 31)) << 2);
+            constexpr int kRowSlot = 0;  // (placeholder so that the next two lines read alike)
+            const int row_off = ((uu + 3) & kMask) * kSlot + kRowSlot, op_off = ((uu + 1) & kMask) * kSlot;
+#pragma unroll
+            for (int t = 0; t < kNSL; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[t], bq, acc[t], 0, 0, 0);
+                if (t < 4) convert_row(t);
+                else if (t == 4) transpose4(lo, tl);
+                else if (t == 5) transpose4(hi, th);
+                __builtin_amdgcn_sched_barrier(0);
+                aop[t] = *reinterpret_cast<const v4i*>(at_next + ((t * MF) << 2));
+                if (t < 4) {
+                    xa[t] = *reinterpret_cast<const double*>(rowA + t * strideA + row_off);
+                    xv[t] = *reinterpret_cast<const double*>(rowB + t * strideB + row_off);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            bq = *reinterpret_cast<const v4i*>(bsrc + op_off);
+            DMFG_STAMP(3)
+            {   // DMA of block b + kRing - 1 into the slot of block b - 1 (its count tile and rows went to registers long
+                // ago), here rather than at the head of the iteration: while this wave waits for the load path to take
+                // the request, the other wave of the SIMD has matrix work to issue
+                const int j = b + kRing - 1, jc = j < nb ? j : nb - 1;  // beyond the range: a repeat keeps the DMA count uniform
+                char* __restrict__ slot = ring + ((uu + kRing - 1) & kMask) * kSlot;
+#pragma unroll
+                for (int x = 0; x < XL; ++x) {
+                    if (x > 0 && wave < 4) break;
+                    int64_t off = (int64_t)jc * gstep[x];
+                    if (tail_clamp && jc == nb - 1) off = off < glim[x] ? off : glim[x];
+                    __builtin_amdgcn_global_load_lds((gmem_void*)(gbase[x] + off), (lds_int*)(slot + lds_dst[x]), 16, 0, 0);
+                }
+            }
+            DMFG_STAMP(5)
+            store_digits(a_gen);
+            a_cur = a_next;
+            DMFG_STAMP(4)
         }
-        bq = *reinterpret_cast<const v4i*>(ring + (j_op % kRing) * kSlot + sg * 1024 + lane * 16);
-        DMFG_STAMP(3)
-        store_digits(a_gen);
-        a_cur = a_next;
-        DMFG_STAMP(4)
     }
     DMFG_STAMP_FLUSH
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (repeat) DMAs must not outlive the workgroup's LDS
@@ -535,7 +575,7 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
     // slab[y][half][feature slot][sample] (i64), as the four-wave kernel writes it
     if (wave_on) {
         const int n = lane & 31, h = lane >> 5;
-        long long* __restrict__ out = slab + ((int64_t)blockIdx.y * 2 * MFtot + p0) * SDs + sb * 32 + n;
+        long long* __restrict__ out = slab + ((int64_t)by * 2 * MFtot + p0) * SDs + sb * 32 + n;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -771,7 +811,7 @@ static hipError_t launch_gram_i8_w8_t(const signed char* Dt8, int64_t plane_stri
         if (e != hipSuccess) return e;
         lds_limit_raised[dev] = true;
     }
-    hipLaunchKernelGGL((k_gram_i8_w8<XL>), dim3(nsh, ny), dim3(512), lds, st, Dt8, plane_stride, SD / 32, Rtp,
+    hipLaunchKernelGGL((k_gram_i8_w8<XL>), dim3(nsh * ny), dim3(512), lds, st, Dt8, plane_stride, SD / 32, Rtp,
                        (n_c + 3) / 4 * 4, u, N, n_c, n_u, fa, fb, NF, p0, MFtot, rpw, slab, SD, done_flag
 #ifdef DMF_STAMPS
                        , (unsigned long long*)nullptr

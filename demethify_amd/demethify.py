@@ -160,7 +160,7 @@ def main(argv=None):
 
     # imported late so that ``--help`` and argument errors work on a box without the GPU library
     from . import _lib as L
-    from . import shard
+    from . import shard, staging
     from .bootstrap import bt_ci
     from .deconvolution import _init_unsupervised, init_BSSMF_md, init_BSSMF_md_p
     from .device import Problem, Solver, get_context
@@ -189,18 +189,27 @@ def main(argv=None):
         if args.restart > 1 and rank == 0:
             print(f"restart k > 0 uses seed + k (upstream repeats the same seed); {args.restart} restarts")
         with Problem(get_context(), meth_f, counts, None if unsupervised else ref) as problem:
-            def solve_one(k, best_cost):
+            if args.restart > 1:
+                staging.reserve(((meth_f.shape[0], n_u), (K, meth_f.shape[1])), count=2)
+
+            def prepare(k):
+                # the restart's initialisation (legacy-numpy draws, NNLS), drawn and uploaded one restart ahead of the
+                # GPU by a worker thread (staging.Prefetcher)
                 seed_k = shard.restart_seed(args.seed, k)
                 if unsupervised:
                     u0, a0 = _init_unsupervised(args.init, meth_f, n_u, seed_k)
-                    mode = L.DMF_MODE_UNSUPERVISED
                 elif purity is not None:
                     u0, _, a0 = init_BSSMF_md_p(args.init, meth_f, counts, ref, n_u, purity, rb_alg=wls_intercept,
                                                 seed=seed_k)
-                    mode = L.DMF_MODE_PARTIAL
                 else:
                     u0, _, a0 = init_BSSMF_md(args.init, meth_f, counts, ref, n_u, rb_alg=wls_intercept, seed=seed_k)
-                    mode = L.DMF_MODE_PARTIAL
+                if args.restart > 1:
+                    return staging.to_device((u0, a0), problem.ctx)
+                return u0, a0
+
+            def solve_one(k, best_cost, prepared):
+                u0, a0 = prepared
+                mode = L.DMF_MODE_UNSUPERVISED if unsupervised else L.DMF_MODE_PARTIAL
                 with Solver(problem, u0, a0, mode) as s:
                     if purity is not None and not unsupervised:
                         s.set_purity(purity)
@@ -212,7 +221,7 @@ def main(argv=None):
                 return u, alpha, cost
 
             ref_estimate, proportions, _best, _costs = shard.sharded_restarts(
-                args.restart, solve_one, ((meth_f.shape[0], n_u), (K, meth_f.shape[1])))
+                args.restart, solve_one, ((meth_f.shape[0], n_u), (K, meth_f.shape[1])), prepare=prepare)
         unknown_header = ["unknown_cell_" + str(i + 1) for i in range(n_u)]
         header = unknown_header if unsupervised else header + unknown_header
     elif n_u == 0 and meth_f.shape[1] >= 1:

@@ -31,7 +31,7 @@ def _host_f64(x, name):
 def _ptr(a):
     if a is None:
         return None
-    if _is_torch(a):
+    if _is_torch(a) or hasattr(a, "data_ptr"):
         return C.c_void_p(a.data_ptr())
     return a.ctypes.data_as(C.c_void_p)
 
@@ -265,17 +265,35 @@ class Solver:
     """dmf_solver: state init (deconvolution.py:192-204) + stepping of the outer loop."""
 
     def __init__(self, problem: Problem, u0, alpha0, mode=L.DMF_MODE_PARTIAL):
+        """u0 (N x n_u) and alpha0 (K x S): host arrays, or BOTH float64 device arrays on the context's GPU
+        (staging.to_device: the initialisation of the next restart, uploaded while this one iterates; or CUDA tensors)."""
         self.problem = problem
         self._lib = problem._lib
-        u0 = np.ascontiguousarray(u0, dtype=np.float64).reshape(problem.N, -1)
-        alpha0 = np.ascontiguousarray(alpha0, dtype=np.float64)
+        flags = 0
+        if getattr(u0, "is_cuda", False) or getattr(alpha0, "is_cuda", False):
+            from .staging import DeviceArray
+
+            for t in (u0, alpha0):
+                if isinstance(t, DeviceArray):
+                    ok = t.ctx is problem.ctx
+                else:
+                    ok = (_is_torch(t) and t.is_cuda and t.is_contiguous() and t.element_size() == 8
+                          and t.is_floating_point() and t.device.index == problem.ctx.device)
+                if not ok:
+                    raise ValueError("u0 and alpha0 must both be host arrays, or both be float64 device arrays "
+                                     "(staging.DeviceArray / contiguous CUDA tensors) on the context's GPU")
+            u0 = u0.reshape(problem.N, -1)
+            flags = L.DMF_PTR_DEVICE
+        else:
+            u0 = np.ascontiguousarray(u0, dtype=np.float64).reshape(problem.N, -1)
+            alpha0 = np.ascontiguousarray(alpha0, dtype=np.float64)
         self.n_u = int(u0.shape[1])
         self.K = problem.n_c + self.n_u
-        if alpha0.shape != (self.K, problem.S):
-            raise ValueError(f"alpha shape {alpha0.shape} != {(self.K, problem.S)}")
+        if tuple(alpha0.shape) != (self.K, problem.S):
+            raise ValueError(f"alpha shape {tuple(alpha0.shape)} != {(self.K, problem.S)}")
         h = C.c_void_p()
         L.check(self._lib.dmf_solver_create(problem.ctx._h, problem._h, _ptr(u0), _ptr(alpha0), self.n_u,
-                                            int(mode), 0, C.byref(h)), "dmf_solver_create")
+                                            int(mode), flags, C.byref(h)), "dmf_solver_create")
         self._h = h
 
     def set_purity(self, purity):

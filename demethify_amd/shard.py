@@ -166,21 +166,36 @@ def restart_seed(seed, k):
     return seed + k
 
 
-def sharded_restarts(n_restarts, solve_one, shapes):
+def sharded_restarts(n_restarts, solve_one, shapes, prepare=None):
     """Run restarts k = 0..n_restarts-1 across the ranks and return the min-cost one everywhere.
 
     solve_one(k, best_cost) -> (u, alpha, cost) runs restart k on this rank's GPU; it may return (None, None,
     cost) when cost >= best_cost (this rank's running minimum: the iterate of a restart that cannot win need not
-    leave the device).  ``shapes`` = (u.shape, alpha.shape) lets non-owner ranks allocate the broadcast buffers.
-    Returns (u, alpha, best_k, cost_vector)."""
+    leave the device).  With ``prepare``, prepare(k) -- the restart's initialisation, possibly already uploaded
+    (staging.to_device) -- runs in ONE worker thread (the initialisers use numpy's global generator) up to two restarts ahead of the GPU and solve_one is called as
+    solve_one(k, best_cost, prepared).  ``shapes`` = (u.shape, alpha.shape) lets non-owner ranks allocate the
+    broadcast buffers.  Returns (u, alpha, best_k, cost_vector)."""
     rank, world, _ = dist_state()
     local_costs, keep = {}, {}
-    for k in my_items(n_restarts, rank, world):
-        u, alpha, cost = solve_one(k, keep["cost"] if keep else float("inf"))
-        local_costs[k] = cost
-        # keep only the local best: strict '<' so that the lowest k wins ties locally as well
-        if not keep or cost < keep["cost"]:
-            keep = {"k": k, "u": u, "alpha": alpha, "cost": cost}
+    mine = list(my_items(n_restarts, rank, world))
+    if prepare is not None:
+        from .staging import Prefetcher
+
+        feed = Prefetcher(mine, prepare, depth=2, workers=1)  # one worker: the reference's initialisers seed numpy's GLOBAL generator
+        source = iter(feed)
+    else:
+        feed, source = None, ((k, None) for k in mine)
+    try:
+        for k, prepared in source:
+            best_cost = keep["cost"] if keep else float("inf")
+            u, alpha, cost = solve_one(k, best_cost) if prepare is None else solve_one(k, best_cost, prepared)
+            local_costs[k] = cost
+            # keep only the local best: strict '<' so that the lowest k wins ties locally as well
+            if not keep or cost < keep["cost"]:
+                keep = {"k": k, "u": u, "alpha": alpha, "cost": cost}
+    finally:
+        if feed is not None:
+            feed.close()
     costs = allreduce_min_vector(local_costs, n_restarts)
     best_k = argmin_first(costs)
     owner = best_k % world

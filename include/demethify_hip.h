@@ -176,6 +176,15 @@ int dmf_table_read(const char* path, char sep, int col_percent_modified, int col
 void* dmf_host_alloc(size_t bytes, int* pinned);
 void dmf_host_free(void* p, int pinned);
 
+/* ---- restart staging.  The reference draws a fresh (u0, alpha0) per restart and solves it, one after the other
+ * (demethify/demethify.py:165-171 and 195-201).  dmf_stage_upload copies a host array (page-locked memory from
+ * dmf_host_alloc makes it a direct DMA) to a new device buffer on a copy stream of the context's own and returns when
+ * the copy is complete; it may be called from a worker thread while the context's stream iterates the restart before.
+ * The buffer is then passed to dmf_solver_create with DMF_PTR_DEVICE and released with dmf_stage_free (ordered behind
+ * the context's stream). */
+int dmf_stage_upload(dmf_context* ctx, const void* host, size_t bytes, void** out_dev);
+int dmf_stage_free(dmf_context* ctx, void* dev);
+
 #ifdef __cplusplus
 }
 #endif

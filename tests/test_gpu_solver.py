@@ -204,3 +204,30 @@ def test_step_is_resumable(ctx):
             u2, a2, c2, _ = s.get()
     assert it == 7 and not conv
     assert np.array_equal(u1, u2) and np.array_equal(a1, a2) and c1 == c2
+
+
+def test_staged_initialisation_is_the_same_solve(toy, ctx):
+    """A restart's (u0, alpha0) uploaded ahead of time (staging.to_device, the restart loop's worker thread) and handed
+    to the solver as device arrays gives bit-identical iterates to the host-array call."""
+    from demethify_amd import _lib as L
+    from demethify_amd import staging
+    from demethify_amd.device import Problem, Solver
+
+    V, D, ref, _ = toy
+    u0, R, a0 = osol.init_partial("uniform_", V, D, ref, 2, seed=3)
+    with Problem(ctx, V, D, ref) as p:
+        with Solver(p, u0, a0, L.DMF_MODE_PARTIAL) as s:
+            s.step(7, 20, 0.0)
+            c_host = s.direct_cost()
+            u_h, a_h, _, _ = s.get()
+        u0_d, a0_d = staging.to_device((u0, a0), ctx)
+        assert u0_d.is_cuda and a0_d.is_cuda
+        with Solver(p, u0_d, a0_d, L.DMF_MODE_PARTIAL) as s:
+            s.step(7, 20, 0.0)
+            c_dev = s.direct_cost()
+            u_d, a_d, _, _ = s.get()
+        with pytest.raises(ValueError):
+            Solver(p, u0_d, a0, L.DMF_MODE_PARTIAL)
+    assert c_host == c_dev
+    np.testing.assert_array_equal(u_h, u_d)
+    np.testing.assert_array_equal(a_h, a_d)

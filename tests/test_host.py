@@ -174,3 +174,58 @@ def test_native_table_reader_is_bit_identical_to_pandas(tmp_path):
     got = tables.read_samples_native([str(single)], False)
     want = _pandas_tables([str(single)], False)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[1].tolist() == [[1], [1]]
+
+
+def test_prefetcher_orders_results_and_propagates_errors():
+    """staging.Prefetcher: fn(item) one ahead, results in order, an exception surfaces at its item."""
+    from demethify_amd.staging import Prefetcher
+
+    seen = []
+
+    def fn(k):
+        seen.append(k)
+        if k == 3:
+            raise RuntimeError("bad restart")
+        return k * k
+
+    out = []
+    pf = Prefetcher(range(3), fn, depth=1)
+    for k, r in pf:
+        out.append((k, r))
+    assert out == [(0, 0), (1, 1), (2, 4)]
+    pf2 = Prefetcher(range(6), fn, depth=1)
+    got = []
+    with pytest.raises(RuntimeError, match="bad restart"):
+        for k, r in pf2:
+            got.append(k)
+    assert got == [0, 1, 2]
+    pf2.close()
+    # a consumer that leaves early lets the worker end
+    pf3 = Prefetcher(range(100), lambda k: k, depth=1)
+    for k, r in pf3:
+        if k == 2:
+            break
+    pf3.close()
+    pf3.join(timeout=5)
+    assert not pf3.is_alive()
+
+
+def test_sharded_restarts_prepare_hook_matches_plain_loop():
+    from demethify_amd import shard
+
+    def prepare(k):
+        return 10 * k
+
+    def solve_plain(k, best):
+        cost = float((k - 2) ** 2)
+        return (np.full((2, 1), k), np.full((1, 2), k), cost)
+
+    def solve_prepared(k, best, prepared):
+        assert prepared == 10 * k
+        return solve_plain(k, best)
+
+    a = shard.sharded_restarts(5, solve_plain, ((2, 1), (1, 2)))
+    b = shard.sharded_restarts(5, solve_prepared, ((2, 1), (1, 2)), prepare=prepare)
+    assert a[2] == b[2] == 2
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[3], b[3])

@@ -32,7 +32,7 @@ int main() {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_gram_i8_w8<1>), dim3(nsh, ny), dim3(512), lds, 0, Dt8, plane, SD / 32, R, 12, u, N, n_c, n_u, dfa, dfb, NF, 0, 64, rpw, slab, SD, (const int*)nullptr
+        hipLaunchKernelGGL((k_gram_i8_w8<1>), dim3(nsh * ny), dim3(512), lds, 0, Dt8, plane, SD / 32, R, 12, u, N, n_c, n_u, dfa, dfb, NF, 0, 64, rpw, slab, SD, (const int*)nullptr
 #ifdef DMF_STAMPS
                            , stamps
 #endif
@@ -45,8 +45,8 @@ int main() {
 #endif
     std::vector<unsigned long long> hs((size_t)nsh * ny * 8 * 8);
     hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost);
-    const char* nm[8] = {"DMA issue", "counted wait (vmcnt, lgkmcnt)", "barrier", "7 MFMA issued", "digits of block b + 2 (drained)",
-                         "operand reads of block b + 1 (drained)", "-", "-"};
+    const char* nm[8] = {"-", "counted wait (vmcnt, lgkmcnt)", "barrier", "7 x (MFMA, conversion piece, LDS refills), drained",
+                         "digit stores", "DMA issue (behind the MFMAs)", "-", "-"};
     double sum[8] = {0}; for (size_t i = 0; i < hs.size(); ++i) sum[i & 7] += (double)hs[i];
     const double waves = (double)nsh * ny * 8, blocks = (double)rpw / 32;
     double tot = 0; for (double x : sum) tot += x;
