@@ -23,7 +23,7 @@ struct SolverState {
     double tol;        // stop threshold of the running step() call (:220)
     long long iters;   // outer iterations completed
     int done;          // 1 once |cf - cf_0| < tol was met; later launches are no-ops
-    int pad;
+    int arrive;        // workgroups of the alpha kernel that have finished this outer iteration (the last one closes it)
 };
 
 // Packed upper triangle, column-major over (k <= l): independent of the matrix size.

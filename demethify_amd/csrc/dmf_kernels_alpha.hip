@@ -241,15 +241,21 @@ __global__ __launch_bounds__(64) void k_project_dyn(const double* __restrict__ X
 }
 
 // Closes one outer iteration: sums the per-block partials and advances the scalar state
-// (deconvolution.py:207, :216-221; a1/a2 advance exactly as the inner loops advanced them).
-__global__ __launch_bounds__(64) void k_finish_iteration(const double* __restrict__ partials, int nb,
-                                                         SolverState* __restrict__ state,
-                                                         int n_iter2) {
-    if (state->done) return;
+// (deconvolution.py:207, :216-221; a1/a2 advance exactly as the inner loops advanced them).  One wave.
+// COHERENT: the partials were written by other workgroups of the SAME launch (the caller is the last workgroup to
+// arrive): read them past this CU's L1.
+template <bool COHERENT>
+__device__ __forceinline__ void finish_iteration_body(const double* __restrict__ partials, int nb, SolverState* __restrict__ state,
+                                                      int n_iter2) {
     double cost = 0.0, n2 = 0.0;
     for (int b = threadIdx.x; b < nb; b += 64) {
-        cost += partials[2 * b];
-        n2 += partials[2 * b + 1];
+        if (COHERENT) {
+            cost += __hip_atomic_load(partials + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            n2 += __hip_atomic_load(partials + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            cost += partials[2 * b];
+            n2 += partials[2 * b + 1];
+        }
     }
     cost = wave_sum(cost);
     n2 = wave_sum(n2);
@@ -270,8 +276,16 @@ __global__ __launch_bounds__(64) void k_finish_iteration(const double* __restric
         state->cf_prev = cf_prev;
         state->cf = cost;
         state->iters += 1;
+        state->arrive = 0;
         if (fabs(cost - cf_prev) < state->tol) state->done = 1;
     }
+}
+
+__global__ __launch_bounds__(64) void k_finish_iteration(const double* __restrict__ partials, int nb,
+                                                         SolverState* __restrict__ state,
+                                                         int n_iter2) {
+    if (state->done) return;
+    finish_iteration_body<false>(partials, nb, state, n_iter2);
 }
 
 __global__ void k_set_lh(SolverState* state) {
@@ -448,8 +462,7 @@ __device__ __forceinline__ void bitonic_step(double& srt, int k, int k2) {
 }
 
 __global__ __launch_bounds__(64) void k_alpha_phase_row16(const double* __restrict__ gb, double* __restrict__ alpha,
-                                                          double* __restrict__ alpha_prev,
-                                                          const SolverState* __restrict__ state, int S, int K,
+                                                          double* __restrict__ alpha_prev, SolverState* state, int S, int K,
                                                           int n_u, int n_iter2, double* __restrict__ partials) {
     if (state->done) return;
     const int lane = threadIdx.x;
@@ -527,18 +540,29 @@ __global__ __launch_bounds__(64) void k_alpha_phase_row16(const double* __restri
     double n2 = (col_ok && row_ok && k >= K - n_u) ? a * a : 0.0;
     part = wave_sum(part);
     n2 = wave_sum(n2);
-    if (lane == 0) {
-        partials[2 * blockIdx.x] = part;
-        partials[2 * blockIdx.x + 1] = n2;
+    if (lane == 0) {  // (agent-scope stores: the closing workgroup may sit on another XCD)
+        __hip_atomic_store(partials + 2 * blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(partials + 2 * blockIdx.x + 1, n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // The last workgroup to arrive closes the outer iteration (what k_finish_iteration does as a launch of its own
+    // behind the other alpha kernels): every other workgroup has read the scalar state long before it incremented the
+    // counter, so advancing the state here races with nobody.  Same summation order as k_finish_iteration.
+    // (no __threadfence(): the partials travel as agent-scope atomic stores, acknowledged -- s_waitcnt vmcnt(0) -- before
+    // the counter is touched; a release fence would write back the XCD's whole L2)
+    int last = 0;
+    if (lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the two stores above are acknowledged
+        last = atomicAdd(&state->arrive, 1) == (int)gridDim.x - 1;
+    }
+    last = __shfl(last, 0, 64);
+    if (last) finish_iteration_body<true>(partials, (int)gridDim.x, state, n_iter2);
 }
 
 static hipError_t launch_alpha_row16(const double* gb, double* alpha, double* alpha_prev, SolverState* state, int S,
                                      int K, int n_u, int n_iter2, double* partials, hipStream_t st) {
     const int nb = (S + 3) / 4;
     hipLaunchKernelGGL(k_alpha_phase_row16, dim3(nb), dim3(64), 0, st, gb, alpha, alpha_prev, state, S, K, n_u,
-                       n_iter2, partials);
-    hipLaunchKernelGGL(k_finish_iteration, dim3(1), dim3(64), 0, st, partials, nb, state, n_iter2);
+                       n_iter2, partials);  // (closes the outer iteration itself)
     return hipGetLastError();
 }
 
@@ -818,7 +842,7 @@ __global__ __launch_bounds__(256) void k_init_state(SolverState* __restrict__ st
         state->tol = 0.0;
         state->iters = 0;
         state->done = 0;
-        state->pad = 0;
+        state->arrive = 0;
     }
 }
 

@@ -7,8 +7,7 @@
 // exact small integer and Z lies in [0, 1], so the GEMM is evaluated WITHOUT rounding: Z is written in fixed point,
 // z ~ rint(z 2^52) = sum_t a_t 256^t with seven balanced 8-bit digits a_t in [-128, 127], the counts likewise as
 // one (d <= 127) or two (d <= 32639) balanced digits, every digit product is accumulated exactly in i32 by
-// v_mfma_i32_32x32x32_i8 and the per-workgroup sums are combined in 64-bit integer arithmetic (k_gram_v2_reduce /
-// k_gram_v2_finish): one conversion to f64 at the very end.  The only rounding against exact arithmetic is rint(z 2^52) of the exact product
+// v_mfma_i32_32x32x32_i8 and the per-workgroup sums are combined in 64-bit integer arithmetic (k_gram_v2_reduce): one conversion to f64 at the very end.  The only rounding against exact arithmetic is rint(z 2^52) of the exact product
 // z = Rt_ik u_ij: |error| <= 2^-53 per feature value, an ulp of 1.0 -- far below a single rounding of an f64
 // accumulation of the same sum (2^-53 RELATIVE to a running sum of ~N d z / 2).  (FP64 needs one FMA per
 // (row, feature, sample); here the same product costs 7 i8 MACs at 64x the FP64 rate.)
@@ -667,32 +666,63 @@ hipError_t launch_bu_cols(const double* V, const unsigned short* D16, int SD, co
 }
 
 // ------------------------------------------------------------------------------------------------ reduce
-// Stage 1 (grid: sample blocks x jobs x kRedChunks): jobs < n_feat add their chunk of the i64 slabs into
-// acc64[half][job][S] with 64-bit integer atomics (exact, so the order of the adds cannot matter); jobs >= n_feat
-// (b_u[j]) sum their chunk of the row pass's f64 slabs in slab order into bu_part[chunk][j][S].
-// Stage 2 (k_gram_v2_finish): gb row of every u-dependent job; acc64 is zeroed again for the next outer iteration.
-constexpr int kRedChunks = 8;
+constexpr int kRedChunks = 16;
 
+// One launch: grid (sample blocks, jobs, kRedChunks).  Jobs < n_feat add their chunk of the i64 slabs into acc64 with
+// 64-bit integer atomics (exact, so the order does not matter); the b_u jobs store their chunk's sum (slab order) into
+// bu_part.  The LAST of a (sample block, job)'s kRedChunks workgroups to arrive -- a counter per column of the grid,
+// reset by that workgroup -- turns the complete sums into the solver's packed Gram rows (atomicExch reads and clears
+// acc64 for the next outer iteration; bu_part is summed in chunk order): the finishing pass is not a launch of its own.
+// Loads are issued four slabs ahead of their use (the loop is a chain of HBM round trips otherwise).
 __global__ __launch_bounds__(256) void k_gram_v2_reduce(const long long* __restrict__ slab_i8, int ny, int MF, int SDs,
                                                         const double* __restrict__ slab_bu, int n_bu_slabs, int n_u,
                                                         int n_feat, int S, unsigned long long* __restrict__ acc64,
-                                                        double* __restrict__ bu_part, const int* __restrict__ done_flag) {
+                                                        double* __restrict__ bu_part, int* __restrict__ arrive,
+                                                        const int* __restrict__ dst_row, double* __restrict__ gb,
+                                                        const int* __restrict__ done_flag,
+                                                        const double* __restrict__ u2_partials, int n_u2,
+                                                        SolverState* __restrict__ state) {
     __shared__ long long part[3][2][64];
     __shared__ double partd[3][64];
+    __shared__ int last_flag;
     if (done_flag != nullptr && *done_flag) return;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int s = blockIdx.x * 64 + lane;
     const int job = blockIdx.y, chunk = blockIdx.z;
     const bool active = s < S;
     const int sc = active ? s : S - 1;
+    if (u2_partials != nullptr && blockIdx.x == 0 && job == 0 && chunk == 0 && grp == 3) {
+        // the row pass's per-workgroup shares of ||u||_F^2 -> state->u_norm2 and l_h (deconvolution.py:212), summed in
+        // workgroup order (needs nothing from this launch: any one wave can do it)
+        double a = 0.0;
+        for (int i = lane; i < n_u2; i += 64) a += u2_partials[i];
+        a = wave_sum(a);
+        if (lane == 0) {
+            state->u_norm2 = a;
+            state->l_h = (state->rt_norm2 + a) * state->dsq;
+        }
+    }
     if (job < n_feat) {
         const int per = (ny + kRedChunks - 1) / kRedChunks;
         const int y0 = chunk * per, y1 = y0 + per < ny ? y0 + per : ny;
+        const int64_t hi_off = (int64_t)MF * SDs, y_stride = (int64_t)2 * MF * SDs;
+        const long long* __restrict__ base = slab_i8 + (int64_t)job * SDs + sc;
         long long lo = 0, hi = 0;
-        for (int y = y0 + grp; y < y1; y += 4) {
-            const long long* __restrict__ base = slab_i8 + ((int64_t)y * 2 * MF + job) * SDs + sc;
-            lo += base[0];
-            hi += base[(int64_t)MF * SDs];
+        for (int y = y0 + grp; y < y1; y += 16) {
+            long long l[4], h[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int yy = y + 4 * q;
+                const long long* __restrict__ b = base + (int64_t)(yy < y1 ? yy : y) * y_stride;
+                l[q] = b[0];
+                h[q] = b[hi_off];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (y + 4 * q < y1) {
+                    lo += l[q];
+                    hi += h[q];
+                }
         }
         if (grp > 0) {
             part[grp - 1][0][lane] = lo;
@@ -711,46 +741,47 @@ __global__ __launch_bounds__(256) void k_gram_v2_reduce(const long long* __restr
         const int c0 = chunk * per, c1 = c0 + per < n_bu_slabs ? c0 + per : n_bu_slabs;
         const int perw = (per + 3) / 4;
         const int g0 = c0 + grp * perw, g1 = g0 + perw < c1 ? g0 + perw : c1;
+        const double* __restrict__ base = slab_bu + (int64_t)j * S + sc;
+        const int64_t g_stride = (int64_t)n_u * S;
         double acc = 0.0;
-        for (int g = g0; g < g1; ++g) acc += slab_bu[((int64_t)g * n_u + j) * S + sc];  // slab order: reproducible
+        for (int g = g0; g < g1; g += 4) {  // slab order: reproducible
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = base[(int64_t)(g + q < g1 ? g + q : g) * g_stride];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (g + q < g1) acc += v[q];
+        }
         if (grp > 0) partd[grp - 1][lane] = acc;
         __syncthreads();
-        if (grp == 0 && active) bu_part[((int64_t)chunk * n_u + j) * S + s] = ((acc + partd[0][lane]) + partd[1][lane]) + partd[2][lane];
+        if (grp == 0 && active)  // (agent-scope store: written through to where the finishing workgroup, on any XCD, reads it)
+            __hip_atomic_store(bu_part + ((int64_t)chunk * n_u + j) * S + s,
+                               ((acc + partd[0][lane]) + partd[1][lane]) + partd[2][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-__global__ __launch_bounds__(64) void k_gram_v2_finish(unsigned long long* __restrict__ acc64, const double* __restrict__ bu_part,
-                                                       int n_u, int n_feat, int S, const int* __restrict__ dst_row,
-                                                       double* __restrict__ gb, const int* __restrict__ done_flag,
-                                                       const double* __restrict__ u2_partials, int n_u2,
-                                                       SolverState* __restrict__ state) {
-    if (done_flag != nullptr && *done_flag) return;
-    if (u2_partials != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {
-        // the row pass's per-workgroup shares of ||u||_F^2 -> state->u_norm2 and l_h (deconvolution.py:212), summed in
-        // workgroup order: one launch less per outer iteration than a kernel of its own
-        double a = 0.0;
-        for (int i = threadIdx.x; i < n_u2; i += 64) a += u2_partials[i];
-        a = wave_sum(a);
-        if (threadIdx.x == 0) {
-            state->u_norm2 = a;
-            state->l_h = (state->rt_norm2 + a) * state->dsq;
-        }
+    // ---- the last workgroup of this (sample block, job) finishes it.  No __threadfence(): an agent-scope release makes
+    // every workgroup write back its XCD's L2 -- with the Gram kernel's 30 MB of slabs still dirty in it that cost 0.29 ms
+    // per launch at the headline shape (measured).  What has to be visible is only what this launch itself adds, and that
+    // travels as agent-scope atomics / atomic stores, which are performed at the memory side; __syncthreads() waits for
+    // their acknowledgements (vmcnt) before the arrival counter is touched.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int* __restrict__ cnt = arrive + (int64_t)job * gridDim.x + blockIdx.x;
+        const int old = atomicAdd(cnt, 1);
+        last_flag = old == (int)gridDim.z - 1;
+        if (last_flag) *cnt = 0;  // ready for the next outer iteration (nobody else touches it any more)
     }
-    const int s = blockIdx.x * 64 + threadIdx.x;
-    const int job = blockIdx.y;
-    if (s >= S) return;
+    __syncthreads();
+    if (!last_flag || grp != 0 || !active) return;
     if (job < n_feat) {
-        unsigned long long* plo = acc64 + (int64_t)job * S + s;
-        unsigned long long* phi = acc64 + ((int64_t)n_feat + job) * S + s;
-        const long long lo = (long long)*plo, hi = (long long)*phi;
-        *plo = 0ull;  // ready for the next outer iteration
-        *phi = 0ull;
+        const long long lo = (long long)atomicExch(acc64 + (int64_t)job * S + s, 0ull);
+        const long long hi = (long long)atomicExch(acc64 + ((int64_t)n_feat + job) * S + s, 0ull);
         // sum = lo + 2^32 hi (an integer of up to ~95 bits) -> f64: the conversions and the FMA round at 2^-53 relative
         gb[(int64_t)dst_row[job] * S + s] = fma((double)hi, 0x1p32, (double)lo) * 0x1p-52;
     } else {
         const int j = job - n_feat;
         double acc = 0.0;
-        for (int c = 0; c < kRedChunks; ++c) acc += bu_part[((int64_t)c * n_u + j) * S + s];
+        for (int c = 0; c < kRedChunks; ++c)
+            acc += __hip_atomic_load(bu_part + ((int64_t)c * n_u + j) * S + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         gb[(int64_t)dst_row[job] * S + s] = acc;
     }
 }
@@ -786,7 +817,8 @@ int64_t gram_i8_slab_words(int64_t N, int SD, int n_c, int n_u) {
 }
 int64_t gram_i8_acc_words(int S, int n_c, int n_u) {
     const int nf = n_c * n_u + n_u * (n_u + 1) / 2;
-    return (int64_t)2 * nf * S + (int64_t)kRedChunks * n_u * S;
+    // + one arrival counter (int) per (job, sample block) of k_gram_v2_reduce's grid
+    return (int64_t)2 * nf * S + (int64_t)kRedChunks * n_u * S + ((int64_t)(nf + n_u) * ((S + 63) / 64) + 1) / 2;
 }
 
 size_t gram_i8_lds_bytes(int nft, int nd, int xl) {
@@ -879,10 +911,10 @@ hipError_t launch_gram_v2_reduce(const long long* slab_i8, int ny, int NF, int S
     const int MF = (NF + 31) / 32 * 32;
     unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(acc_words);
     double* bu_part = reinterpret_cast<double*>(acc_words + (int64_t)2 * NF * S);
+    int* arrive = reinterpret_cast<int*>(acc_words + (int64_t)2 * NF * S + (int64_t)kRedChunks * n_u * S);  // zero at rest
     hipLaunchKernelGGL(k_gram_v2_reduce, dim3((S + 63) / 64, NF + n_u, kRedChunks), dim3(256), 0, st, slab_i8, ny, MF, SD,
-                       slab_bu, n_bu_slabs, n_u, NF, S, acc64, bu_part, done_flag);
-    hipLaunchKernelGGL(k_gram_v2_finish, dim3((S + 63) / 64, NF + n_u), dim3(64), 0, st, acc64, bu_part, n_u, NF, S, dst_row,
-                       gb, done_flag, u2_partials, n_u2, state);
+                       slab_bu, n_bu_slabs, n_u, NF, S, acc64, bu_part, arrive, dst_row, gb, done_flag, u2_partials, n_u2,
+                       state);
     return hipGetLastError();
 }
 
