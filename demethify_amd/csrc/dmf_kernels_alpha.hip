@@ -242,16 +242,17 @@ __global__ __launch_bounds__(64) void k_project_dyn(const double* __restrict__ X
 
 // Closes one outer iteration: sums the per-block partials and advances the scalar state
 // (deconvolution.py:207, :216-221; a1/a2 advance exactly as the inner loops advanced them).  One wave.
-// COHERENT: the partials were written by other workgroups of the SAME launch (the caller is the last workgroup to
-// arrive): read them past this CU's L1.
+// COHERENT: the partials were handed over by other workgroups of the SAME launch as atomic exchanges (the caller is
+// the last workgroup to arrive): collected with atomics too.
 template <bool COHERENT>
 __device__ __forceinline__ void finish_iteration_body(const double* __restrict__ partials, int nb, SolverState* __restrict__ state,
                                                       int n_iter2) {
     double cost = 0.0, n2 = 0.0;
     for (int b = threadIdx.x; b < nb; b += 64) {
         if (COHERENT) {
-            cost += __hip_atomic_load(partials + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            n2 += __hip_atomic_load(partials + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long* pp = reinterpret_cast<unsigned long long*>(const_cast<double*>(partials)) + 2 * b;
+            cost += __longlong_as_double((long long)atomicOr(pp, 0ull));
+            n2 += __longlong_as_double((long long)atomicOr(pp + 1, 0ull));
         } else {
             cost += partials[2 * b];
             n2 += partials[2 * b + 1];
@@ -540,20 +541,19 @@ __global__ __launch_bounds__(64) void k_alpha_phase_row16(const double* __restri
     double n2 = (col_ok && row_ok && k >= K - n_u) ? a * a : 0.0;
     part = wave_sum(part);
     n2 = wave_sum(n2);
-    if (lane == 0) {  // (agent-scope stores: the closing workgroup may sit on another XCD)
-        __hip_atomic_store(partials + 2 * blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(partials + 2 * blockIdx.x + 1, n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int last = 0;
+    if (lane == 0) {
+        // handed to the closing workgroup as returning atomic exchanges (see k_gram_v2_reduce: all atomics on an address
+        // are performed in one place and a returned value means "performed"), then this workgroup's arrival is counted
+        unsigned long long* __restrict__ pp = reinterpret_cast<unsigned long long*>(partials) + 2 * blockIdx.x;
+        const unsigned long long r0 = atomicExch(pp, (unsigned long long)__double_as_longlong(part));
+        const unsigned long long r1 = atomicExch(pp + 1, (unsigned long long)__double_as_longlong(n2));
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(r0), "v"(r1) : "memory");
+        last = atomicAdd(&state->arrive, 1) == (int)gridDim.x - 1;
     }
     // The last workgroup to arrive closes the outer iteration (what k_finish_iteration does as a launch of its own
     // behind the other alpha kernels): every other workgroup has read the scalar state long before it incremented the
     // counter, so advancing the state here races with nobody.  Same summation order as k_finish_iteration.
-    // (no __threadfence(): the partials travel as agent-scope atomic stores, acknowledged -- s_waitcnt vmcnt(0) -- before
-    // the counter is touched; a release fence would write back the XCD's whole L2)
-    int last = 0;
-    if (lane == 0) {
-        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the two stores above are acknowledged
-        last = atomicAdd(&state->arrive, 1) == (int)gridDim.x - 1;
-    }
     last = __shfl(last, 0, 64);
     if (last) finish_iteration_body<true>(partials, (int)gridDim.x, state, n_iter2);
 }

@@ -732,8 +732,10 @@ __global__ __launch_bounds__(256) void k_gram_v2_reduce(const long long* __restr
         if (grp == 0 && active && y0 < y1) {
             lo += part[0][0][lane] + part[1][0][lane] + part[2][0][lane];
             hi += part[0][1][lane] + part[1][1][lane] + part[2][1][lane];
-            atomicAdd(acc64 + (int64_t)job * S + s, (unsigned long long)lo);
-            atomicAdd(acc64 + ((int64_t)n_feat + job) * S + s, (unsigned long long)hi);
+            // (returning atomics, the returns consumed: see the hand-over below)
+            const unsigned long long r0 = atomicAdd(acc64 + (int64_t)job * S + s, (unsigned long long)lo);
+            const unsigned long long r1 = atomicAdd(acc64 + ((int64_t)n_feat + job) * S + s, (unsigned long long)hi);
+            asm volatile("" ::"v"(r0), "v"(r1));
         }
     } else {
         const int j = job - n_feat;
@@ -754,15 +756,21 @@ __global__ __launch_bounds__(256) void k_gram_v2_reduce(const long long* __restr
         }
         if (grp > 0) partd[grp - 1][lane] = acc;
         __syncthreads();
-        if (grp == 0 && active)  // (agent-scope store: written through to where the finishing workgroup, on any XCD, reads it)
-            __hip_atomic_store(bu_part + ((int64_t)chunk * n_u + j) * S + s,
-                               ((acc + partd[0][lane]) + partd[1][lane]) + partd[2][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (grp == 0 && active) {  // (handed over as a returning atomic exchange, like the integer sums: see below)
+            const double v = ((acc + partd[0][lane]) + partd[1][lane]) + partd[2][lane];
+            const unsigned long long r = atomicExch(reinterpret_cast<unsigned long long*>(bu_part) + ((int64_t)chunk * n_u + j) * S + s,
+                                                    (unsigned long long)__double_as_longlong(v));
+            asm volatile("" ::"v"(r));
+        }
     }
-    // ---- the last workgroup of this (sample block, job) finishes it.  No __threadfence(): an agent-scope release makes
-    // every workgroup write back its XCD's L2 -- with the Gram kernel's 30 MB of slabs still dirty in it that cost 0.29 ms
-    // per launch at the headline shape (measured).  What has to be visible is only what this launch itself adds, and that
-    // travels as agent-scope atomics / atomic stores, which are performed at the memory side; __syncthreads() waits for
-    // their acknowledgements (vmcnt) before the arrival counter is touched.
+    // ---- the last workgroup of this (sample block, job) finishes it.  The hand-over uses atomics only: every value a
+    // workgroup contributes goes out as a RETURNING atomic (add / exchange) whose return is awaited (__syncthreads()
+    // drains vmcnt) before the workgroup's arrival is counted, and the finishing workgroup -- the one whose own counter
+    // atomic returned gridDim.z - 1 -- collects with atomic exchanges.  All atomics on an address are performed in one
+    // place, and a returned value means "performed", so the last arrival sees every contribution.  (An agent-scope
+    // __threadfence() instead made every wave write back its XCD's L2: +0.29 ms per launch at the headline shape.
+    // No-return atomics are acknowledged before they are performed: with them the finishing workgroup now and then
+    // missed a chunk, which tests/test_gpu_bench_paths.py caught as a 1e-5 error in one run out of three.)
     __syncthreads();
     if (threadIdx.x == 0) {
         int* __restrict__ cnt = arrive + (int64_t)job * gridDim.x + blockIdx.x;
@@ -780,8 +788,9 @@ __global__ __launch_bounds__(256) void k_gram_v2_reduce(const long long* __restr
     } else {
         const int j = job - n_feat;
         double acc = 0.0;
-        for (int c = 0; c < kRedChunks; ++c)
-            acc += __hip_atomic_load(bu_part + ((int64_t)c * n_u + j) * S + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int c = 0; c < kRedChunks; ++c)  // chunk order: reproducible
+            acc += __longlong_as_double((long long)atomicExch(
+                reinterpret_cast<unsigned long long*>(bu_part) + ((int64_t)c * n_u + j) * S + s, 0ull));
         gb[(int64_t)dst_row[job] * S + s] = acc;
     }
 }

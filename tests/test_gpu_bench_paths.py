@@ -206,3 +206,31 @@ def test_config5_shape_properties(ctx):
     assert np.all(np.isfinite(scores[0]))
     assert np.allclose(scores[0], scores[3], rtol=1e-9)
     assert int(np.argmin(scores[0])) == int(np.argmin(scores[3]))
+
+
+@pytest.mark.parametrize("N,S,n_c,n_u,depth", [(1500, 64, 16, 4, 2500), (4096, 256, 12, 4, 60), (20000, 64, 6, 2, 40)])
+def test_in_launch_hand_overs_are_race_free(ctx, N, S, n_c, n_u, depth):
+    """The Gram reduce finishes its own columns in the last workgroup to arrive and the K <= 16 alpha kernel closes the
+    outer iteration the same way (atomics-only hand-over, no kernel boundary in between).  The sums involved are exact
+    integers or fixed-order f64 sums, so every repetition of a solve must give the SAME BITS; a missed or late
+    contribution (seen once with no-return atomics: 1e-5 relative, one run in three) shows up as a difference."""
+    from demethify_amd import _lib as L
+    from demethify_amd.device import Problem, Solver
+
+    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=5, depth=depth)
+    rng = np.random.RandomState(4)
+    u0 = rng.uniform(size=(N, n_u))
+    a0 = rng.dirichlet(np.ones(n_c + n_u), S).T.copy()
+    first = None
+    with Problem(ctx, V, D, Rt) as p:
+        for rep in range(40):
+            with Solver(p, u0, a0, L.DMF_MODE_PARTIAL) as s:
+                assert "gram=k_gram_i8" in s.describe(20)
+                s.step(4, 20, 0.0)
+                u, alpha, cost, _ = s.get()
+            if first is None:
+                first = (u, alpha, cost)
+            else:
+                assert cost == first[2], rep
+                np.testing.assert_array_equal(alpha, first[1], err_msg=f"repetition {rep}")
+                np.testing.assert_array_equal(u, first[0], err_msg=f"repetition {rep}")
