@@ -56,6 +56,7 @@ SIGNATURES = {
     "dmf_table_read": (C.c_int, [C.c_char_p, C.c_char, C.c_int, C.c_int, _i64, _p, _i64, C.c_double, _p, _i64, C.c_int]),
     "dmf_host_alloc": (_p, [C.c_size_t, C.POINTER(C.c_int)]),
     "dmf_host_free": (None, [_p, C.c_int]),
+    "dmf_write_interval_csv": (C.c_int, [C.c_char_p, C.c_char_p, _p, _p, _i64, C.c_int, C.c_int, C.c_int]),
     "dmf_stage_upload": (C.c_int, [_p, _p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "dmf_stage_free": (C.c_int, [_p, _p]),
     "dmf_solve": (C.c_int, [_p, _p, _p, _p, _i64, C.c_int, _i64, _i64, C.c_double, C.c_int, _p, _p,

@@ -10,6 +10,7 @@ re-partitioned by CpG range with one all-to-all.
 """
 from __future__ import annotations
 
+import os
 import queue
 import threading
 
@@ -54,8 +55,10 @@ def _device_stack(n_local, width):
 
 
 def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, n_iter1, n_iter2, tol, header,
-          outdir, samples, purity, seed):
-    """bootstrap.py:10-93 -> [proportions CI DataFrame, (profile CI DataFrame)]; writes the two CSVs."""
+          outdir, samples, purity, seed, materialize=True):
+    """bootstrap.py:10-93 -> [proportions CI DataFrame, (profile CI DataFrame)]; writes the two CSVs.
+    materialize=False (the CLI, which ignores the return value) skips building the N-row DataFrame of tuples for the
+    profile intervals: the CSV is written by the library and the second result is the (lower, upper) array pair."""
     purity_frac = None
     if purity:
         # upstream quirk kept: bt_ci takes the raw percentages and uses p / 100 (bootstrap.py:18) while main()
@@ -157,8 +160,35 @@ def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, 
         bounds = shard.percentile_over_replicates(local_u, n_bootstrap, q, get_context().percentile_axis0)
         if bounds is not None:
             lower_u, upper_u = (b.reshape(n_rows, n_u) for b in bounds)  # by resampled position, as upstream
-            ref_estimate_df = pd.DataFrame({unknown_header[k]: [(lower_u[j, k], upper_u[j, k]) for j in range(n_rows)]
-                                            for k in range(n_u)})
-            ref_estimate_df.to_csv(outdir + "/confidence_interval_methylation_estimate.csv", index=False)
-            results.append(ref_estimate_df)
+            path = outdir + "/confidence_interval_methylation_estimate.csv"
+            if not _write_interval_csv(path, unknown_header, lower_u, upper_u) or materialize:
+                # upstream's way (bootstrap.py:85-91): N Python tuples per column through DataFrame.to_csv, ~20 s at 1e6 rows
+                ref_estimate_df = pd.DataFrame({unknown_header[k]: [(lower_u[j, k], upper_u[j, k]) for j in range(n_rows)]
+                                                for k in range(n_u)})
+                if not os.path.exists(path):
+                    ref_estimate_df.to_csv(path, index=False)
+                results.append(ref_estimate_df)
+            else:
+                results.append((lower_u, upper_u))
     return results
+
+
+def _write_interval_csv(path, columns, lower, upper) -> bool:
+    """The (lower, upper) table as DataFrame.to_csv writes a DataFrame of tuples, by the library's writer
+    (dmf_write_interval_csv: byte-identical, tests/test_host.py).  False if a column name would need CSV quoting."""
+    import ctypes as C
+
+    if any(ch in name for name in columns for ch in ',"\r\n'):
+        return False
+    lib = L.load()
+    lower = np.ascontiguousarray(lower, dtype=np.float64)
+    upper = np.ascontiguousarray(upper, dtype=np.float64)
+    numpy_scalar_repr = int(str((np.float64(0.5),)).startswith("(np.float64("))  # numpy >= 2 prints scalars that way
+    try:
+        os.remove(path)
+    except OSError:
+        pass
+    rc = lib.dmf_write_interval_csv(path.encode(), ",".join(columns).encode(), lower.ctypes.data_as(C.c_void_p),
+                                    upper.ctypes.data_as(C.c_void_p), lower.shape[0], lower.shape[1], numpy_scalar_repr,
+                                    min(16, os.cpu_count() or 1))
+    return rc == 0

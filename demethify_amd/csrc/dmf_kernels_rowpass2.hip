@@ -216,37 +216,52 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
     constexpr int RPWB = 64 / NU;  // >= 16 rows per wave: one phase-B pass covers the block
     const int rl = lane / NU, jb = lane - rl * NU;
     const bool b_lane = rl < 16 && rl < RPWB;
+    // The block's loads are BUFFER loads: address = descriptor base (scalar: array + block offset, recomputed per block on
+    // the scalar unit) + a loop-invariant per-lane byte offset + a scalar / immediate offset per instruction -- no vector
+    // address arithmetic at all (the flat-address form of this prefetch cost ~80 vector instructions per block and wave,
+    // and the row pass is bound by the SIMD's issue slots).  The descriptor's range check replaces the clamps of the
+    // last, partial block: rows at or beyond N read as zero, and their counts are zero.
+    const unsigned int v_off = (unsigned int)(ld_row * S + ld_gcol) * 8u;               // V: row ld_row of a row pair
+    const unsigned int d_off = (unsigned int)(d_row * SD + wcol0 + d_col) * 2u;         // counts: row d_row of eight
+    const unsigned int r_off = (unsigned int)(m16 * NCT + q) * 8u;                      // R_trunc (padded copy): row m16
+    const unsigned int u_off = b_lane ? (unsigned int)lane * 8u : 0xFFFFFFF0u;          // u / u_: (row, unknown) = lane
+    auto span = [](int64_t bytes) { return (unsigned int)(bytes < 0 ? 0 : (bytes > 0x7FFFFFFF ? 0x7FFFFFFF : bytes)); };
     auto prefetch = [&](int64_t blk) {
         const int64_t r0 = blk * 16;
+        const int64_t left = N - r0;  // rows of the arrays from this block on (> 0)
         {
             // FIRST in the batch: the tile store's wait for the (younger) tile loads then covers them, and phase B
             // finds its u / u_ complete without a vmcnt wait of its own -- a wait there would also cover the NEXT
             // block's prefetch, issued just before barrier X, and put a whole HBM round trip on the critical path.
-            // (unconditional on purpose: loads under a branch make the compiler's s_waitcnt placement pessimistic)
-            const int64_t gi = (b_lane && r0 + rl < N) ? (r0 + rl) * NU + jb : 0;
-            pu = u[gi];
-            pup = u_prev[gi];
+            const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(u + r0 * NU), 0, span(left * NU * 8), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(u_prev + r0 * NU), 0, span(left * NU * 8), 0x00020000);
+            const v2u a = __builtin_amdgcn_raw_buffer_load_b64(ru, u_off, 0, 0);
+            const v2u b = __builtin_amdgcn_raw_buffer_load_b64(rp, u_off, 0, 0);
+            pu = __hiloint2double((int)a.y, (int)a.x);
+            pup = __hiloint2double((int)b.y, (int)b.x);
         }
-        if (r0 + 16 <= N) {  // (wave-uniform)
-            const double* __restrict__ rb = Rtp + r0 * NCT + m16 * NCT + q;
+        if (NKC > 0) {
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(Rtp + r0 * NCT), 0, span(left * NCT * 8), 0x00020000);
 #pragma unroll
-            for (int kc = 0; kc < NKC; ++kc) nrt[kc] = rb[kc * 4];
-            const double* __restrict__ vb = V + r0 * S + ld_row * S + ld_gcol;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) pv[i] = *reinterpret_cast<const v2d*>(vb + (2 * i) * S);
-        } else {  // last, partial block: rows beyond N read row N - 1 (their counts are zero)
-            const int64_t rr = r0 + m16 < N ? r0 + m16 : N - 1;
-#pragma unroll
-            for (int kc = 0; kc < NKC; ++kc) nrt[kc] = Rtp[rr * NCT + kc * 4 + q];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int64_t rv = r0 + 2 * i + ld_row < N ? r0 + 2 * i + ld_row : N - 1;
-                pv[i] = *reinterpret_cast<const v2d*>(V + rv * S + ld_gcol);
+            for (int kc = 0; kc < NKC; ++kc) {
+                const v2u a = __builtin_amdgcn_raw_buffer_load_b64(rr, r_off, kc * 32, 0);
+                nrt[kc] = __hiloint2double((int)a.y, (int)a.x);
             }
         }
-        const unsigned short* __restrict__ db = D16 + (r0 + d_row) * SD + wcol0 + d_col;
-        pd[0] = *reinterpret_cast<const v4u*>(db);
-        pd[1] = *reinterpret_cast<const v4u*>(db + (int64_t)8 * SD);
+        {
+            const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(V + r0 * S), 0, span(left * S * 8), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const v4u a = __builtin_amdgcn_raw_buffer_load_b128(rv, v_off, 2 * i * S * 8, 0);
+                pv[i] = v2d{__hiloint2double((int)a.y, (int)a.x), __hiloint2double((int)a.w, (int)a.z)};
+            }
+        }
+        {
+            // (the count copy is zero-padded to whole blocks of 16 rows: always in range)
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(D16 + r0 * SD), 0, span((int64_t)16 * SD * 2), 0x00020000);
+            pd[0] = __builtin_amdgcn_raw_buffer_load_b128(rd, d_off, 0, 0);
+            pd[1] = __builtin_amdgcn_raw_buffer_load_b128(rd, d_off, 8 * SD * 2, 0);
+        }
     };
     if (nk > 0) prefetch(blockIdx.x);
 
@@ -282,7 +297,6 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
         // the block's u / u_ arrived with the tile (the next prefetch reuses pu / pup before phase B runs)
         const bool my_turn = wave == s % NW;
         const bool ok = b_lane && row0 + rl < N;
-        const int64_t gi = ok ? (row0 + rl) * NU + jb : 0;
         const double uu0 = pu;
         const double up0 = pup;
         __builtin_amdgcn_wave_barrier();
@@ -410,8 +424,11 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
             }
             if (b_lane) ubuf[rl * NU + jb] = ok ? uu : 0.0;  // rows beyond N: phase C multiplies them by zero counts
             if (ok) {
-                u[gi] = uu;
-                u_prev[gi] = up;
+                // (buffer stores, like the loads: scalar base of the block + this lane's constant offset)
+                const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)(u + row0 * NU), 0, span((N - row0) * NU * 8), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(u_prev + row0 * NU), 0, span((N - row0) * NU * 8), 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b64(v2u{(unsigned int)__double2loint(uu), (unsigned int)__double2hiint(uu)}, ru, u_off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(v2u{(unsigned int)__double2loint(up), (unsigned int)__double2hiint(up)}, rp, u_off, 0, 0);
                 u2_acc = fma(uu, uu, u2_acc);
             }
             __builtin_amdgcn_s_setprio(0);

@@ -17,6 +17,9 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <charconv>
+#include <cmath>
+#include <string>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -260,6 +263,132 @@ int dmf_table_read(const char* path, char sep, int col_percent_modified, int col
     return status.load();
 }
 
+}  // extern "C"
+
+namespace {
+
+// repr(float) of CPython / numpy (shortest digits that round-trip; fixed notation while -4 < decimal exponent <= 16,
+// else d.ddde+XX with at least two exponent digits; a trailing ".0" on integers).  Appends to `out`.
+void append_py_repr(std::string& out, double x) {
+    if (std::isnan(x)) {
+        out += "nan";
+        return;
+    }
+    if (std::isinf(x)) {
+        out += x < 0 ? "-inf" : "inf";
+        return;
+    }
+    if (std::signbit(x)) {
+        out += '-';
+        x = -x;
+    }
+    if (x == 0.0) {
+        out += "0.0";
+        return;
+    }
+    char buf[48];
+    const auto r = std::to_chars(buf, buf + sizeof(buf), x, std::chars_format::scientific);  // shortest round trip
+    // buf = d[.ddd]e[+-]XX
+    char digits[24];
+    int nd = 0;
+    const char* p = buf;
+    for (; p < r.ptr && *p != 'e'; ++p)
+        if (*p != '.') digits[nd++] = *p;
+    int e10 = 0;
+    {
+        ++p;  // 'e'
+        const bool neg = *p == '-';
+        ++p;
+        for (; p < r.ptr; ++p) e10 = e10 * 10 + (*p - '0');
+        if (neg) e10 = -e10;
+    }
+    const int decpt = e10 + 1;  // value = 0.d1d2... x 10^decpt
+    if (decpt > -4 && decpt <= 16) {
+        if (decpt <= 0) {
+            out += "0.";
+            out.append((size_t)(-decpt), '0');
+            out.append(digits, (size_t)nd);
+        } else if (decpt >= nd) {
+            out.append(digits, (size_t)nd);
+            out.append((size_t)(decpt - nd), '0');
+            out += ".0";
+        } else {
+            out.append(digits, (size_t)decpt);
+            out += '.';
+            out.append(digits + decpt, (size_t)(nd - decpt));
+        }
+    } else {
+        out += digits[0];
+        if (nd > 1) {
+            out += '.';
+            out.append(digits + 1, (size_t)(nd - 1));
+        }
+        out += 'e';
+        int e = decpt - 1;
+        out += e < 0 ? '-' : '+';
+        if (e < 0) e = -e;
+        char eb[8];
+        int ne = 0;
+        do {
+            eb[ne++] = (char)('0' + e % 10);
+            e /= 10;
+        } while (e > 0);
+        if (ne < 2) eb[ne++] = '0';
+        while (ne > 0) out += eb[--ne];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* The confidence-interval table of the profile estimates as the reference writes it (demethify/bootstrap.py:85-91: a
+ * DataFrame whose cells are (lower, upper) tuples, DataFrame.to_csv): header line, then per CpG row the n_cols cells
+ * "(lo, hi)" -- quoted, because of the comma -- with the floats as repr() prints them.  numpy_scalar_repr != 0 writes
+ * the cells as numpy >= 2 prints a tuple of float64 scalars, "(np.float64(lo), np.float64(hi))".  Byte-identical to the
+ * pandas output (tests/test_host.py); 1e6 rows take a fraction of a second instead of ~20 s. */
+int dmf_write_interval_csv(const char* path, const char* header_line, const double* lower, const double* upper,
+                           int64_t n_rows, int n_cols, int numpy_scalar_repr, int n_threads) {
+    if (!path || !header_line || !lower || !upper || n_rows < 0 || n_cols < 1) return DMF_ERR_BAD_ARG;
+    FILE* f = fopen(path, "wb");
+    if (!f) return DMF_ERR_BAD_ARG;
+    bool ok = fputs(header_line, f) >= 0 && fputc('\n', f) != EOF;
+    if (n_threads < 1) n_threads = 1;
+    const int64_t kBatch = 65536;  // rows per thread and round
+    const char* open_lo = numpy_scalar_repr ? "\"(np.float64(" : "\"(";
+    const char* mid = numpy_scalar_repr ? "), np.float64(" : ", ";
+    const char* close_hi = numpy_scalar_repr ? "))\"" : ")\"";
+    std::vector<std::string> bufs((size_t)n_threads);
+    for (int64_t r0 = 0; r0 < n_rows && ok; r0 += kBatch * n_threads) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t)
+            th.emplace_back([&, t] {
+                std::string& out = bufs[(size_t)t];
+                out.clear();
+                const int64_t a = r0 + t * kBatch, b = a + kBatch < n_rows ? a + kBatch : n_rows;
+                for (int64_t i = a; i < b; ++i) {
+                    for (int c = 0; c < n_cols; ++c) {
+                        if (c) out += ',';
+                        out += open_lo;
+                        append_py_repr(out, lower[i * n_cols + c]);
+                        out += mid;
+                        append_py_repr(out, upper[i * n_cols + c]);
+                        out += close_hi;
+                    }
+                    out += '\n';
+                }
+            });
+        for (auto& x : th) x.join();
+        for (int t = 0; t < n_threads && ok; ++t)
+            if (!bufs[(size_t)t].empty()) ok = fwrite(bufs[(size_t)t].data(), 1, bufs[(size_t)t].size(), f) == bufs[(size_t)t].size();
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? DMF_OK : DMF_ERR_BAD_ARG;
+}
+
+}  // extern "C"
+
+extern "C" {
 /* Page-locked host memory for the input matrices (falls back to plain memory without a GPU runtime). */
 void* dmf_host_alloc(size_t bytes, int* pinned) {
     void* p = nullptr;

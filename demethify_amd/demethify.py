@@ -173,7 +173,8 @@ def main(argv=None):
 
     if args.confidence:
         bt_ci(args.confidence[0], args.confidence[1], n_u, meth_f, counts, ref, args.init, args.iterations[0],
-              args.iterations[1], args.termination, header, outdir, args.methfreq, args.purity, args.seed)
+              args.iterations[1], args.termination, header, outdir, args.methfreq, args.purity, args.seed,
+              materialize=False)
 
     if args.ic:
         ref_estimate, proportions, ic_n_u, _scores = evaluate_best_ic(

@@ -176,6 +176,13 @@ int dmf_table_read(const char* path, char sep, int col_percent_modified, int col
 void* dmf_host_alloc(size_t bytes, int* pinned);
 void dmf_host_free(void* p, int pinned);
 
+/* ---- output tables.  The profile confidence intervals go out as the reference writes them (demethify/bootstrap.py:85-91:
+ * a DataFrame of (lower, upper) tuples through DataFrame.to_csv): header_line, then per row the n_cols quoted cells
+ * "(lo, hi)" -- or "(np.float64(lo), np.float64(hi))" with numpy_scalar_repr != 0, what numpy >= 2 makes of the same
+ * tuple -- floats as repr() prints them.  lower / upper are row-major (n_rows x n_cols).  Byte-identical to pandas. */
+int dmf_write_interval_csv(const char* path, const char* header_line, const double* lower, const double* upper,
+                           int64_t n_rows, int n_cols, int numpy_scalar_repr, int n_threads);
+
 /* ---- restart staging.  The reference draws a fresh (u0, alpha0) per restart and solves it, one after the other
  * (demethify/demethify.py:165-171 and 195-201).  dmf_stage_upload copies a host array (page-locked memory from
  * dmf_host_alloc makes it a direct DMA) to a new device buffer on a copy stream of the context's own and returns when

@@ -229,3 +229,30 @@ def test_sharded_restarts_prepare_hook_matches_plain_loop():
     assert a[2] == b[2] == 2
     np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[3], b[3])
+
+
+def test_interval_csv_writer_is_byte_identical_to_pandas(tmp_path):
+    """dmf_write_interval_csv (the profile confidence intervals, bootstrap.py:85-91 upstream) against DataFrame.to_csv of a
+    DataFrame of (lower, upper) tuples: same bytes, including the float spellings repr() has for small, large, integral,
+    negative-zero and non-finite values."""
+    import pandas as pd
+
+    from demethify_amd.bootstrap import _write_interval_csv
+
+    rng = np.random.RandomState(3)
+    n_rows, n_u = 5000, 3
+    lower = rng.rand(n_rows, n_u)
+    upper = lower + rng.rand(n_rows, n_u) * 1e-3
+    special = [0.0, 1.0, 1e-5, 1e-4, 1.5e-7, 0.1 + 0.2, 5e-324, 123456789.0, 1e16, 1e15, 0.5, 2.5e-5, 1e22,
+               1.7976931348623157e308, 9.999999999999999e-5, 0.00011, 12345678901234567.0, float("nan"), float("inf"),
+               -0.0, -3.25, 2.0 ** -1074, 1 / 3, 2 / 3, 1e-310]
+    for i, v in enumerate(special):
+        lower[i, i % n_u] = v
+        upper[(7 * i) % n_rows, (i + 1) % n_u] = v
+    cols = [f"unknown_cell_{k + 1}" for k in range(n_u)]
+    want = tmp_path / "pandas.csv"
+    pd.DataFrame({cols[k]: [(lower[j, k], upper[j, k]) for j in range(n_rows)] for k in range(n_u)}).to_csv(want, index=False)
+    got = tmp_path / "native.csv"
+    assert _write_interval_csv(str(got), cols, lower, upper)
+    assert got.read_bytes() == want.read_bytes()
+    assert not _write_interval_csv(str(got), ["a,b", "c", "d"], lower, upper)  # a header that needs quoting: pandas' job

@@ -24,7 +24,7 @@ ref = np.ascontiguousarray(Rfull[:, :n_c])
 with tempfile.TemporaryDirectory() as out:
     t0 = time.perf_counter()
     bt_ci(95, B, n_u, V, D.astype(np.int64), ref, "uniform_", T1, 20, 0.0, [f"t{k}" for k in range(n_c)], out,
-          [f"s{k}" for k in range(S)], None, 1)
+          [f"s{k}" for k in range(S)], None, 1, materialize=False)  # as the CLI calls it
     dt = time.perf_counter() - t0
 print(f"{B} replicates x {T1} outer iterations at {N} x {S}, {n_c}+{n_u}: {dt:.2f} s wall incl. upload, percentiles and CSV "
       f"writing -> {B / dt:.2f} replicates/s")
