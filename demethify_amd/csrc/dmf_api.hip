@@ -1046,7 +1046,8 @@ int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t
     if (s->use_v2 && n_iter2 <= kSplitInnerSteps && dmf::rowpass_v2_supported(S, n_c, n_u, (int)n_iter2)) {
         snprintf(row, sizeof(row), "k_rowpass_v2<%d,%d> nw=%d grid=%d tail=%d", (n_c + 3) / 4, n_u, (S + 63) / 64,
                  dmf::rowpass_v2_grid(p->N, S), (int)(p->N & 15));
-        snprintf(gram, sizeof(gram), "k_gram_i8<nd=%d>", p->ND);
+        // (one count digit and more than 32 features: the eight-wave form of the integer Gram kernel takes the first 64)
+        snprintf(gram, sizeof(gram), "k_gram_i8<nd=%d>%s", p->ND, p->ND == 1 && n_c * n_u + n_u * (n_u + 1) / 2 > 32 ? "/w8" : "");
     } else if (s->use_fused && n_iter2 <= kSplitInnerSteps) {
         const int64_t n_full = p->N - (p->N & 15);
         snprintf(row, sizeof(row), "k_rowpass_fused<%d,%d> nw=%d grid=%d tail=%d", (n_c + 3) / 4, n_u, (S + 63) / 64,
@@ -1058,7 +1059,9 @@ int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t
         else if (s->u_path == 0) snprintf(row, sizeof(row), "k_u_phase_mfma");
         else if (s->u_path == 1) snprintf(row, sizeof(row), "k_u_phase_gram");
         else snprintf(row, sizeof(row), "k_u_step_direct");
-        if (s->use_gram_i8) snprintf(gram, sizeof(gram), "k_bu_cols+k_gram_i8<nd=%d>", p->ND);
+        if (s->use_gram_i8)
+            snprintf(gram, sizeof(gram), "k_bu_cols+k_gram_i8<nd=%d>%s", p->ND,
+                     p->ND == 1 && n_c * n_u + n_u * (n_u + 1) / 2 > 32 ? "/w8" : "");
         else snprintf(gram, sizeof(gram), "%s", s->use_gram_spec ? "k_gram_u" : s->use_gram_mfma ? "k_gram_mfma" : "k_gram");
     }
     const bool tps = s->ctx->generic_level == 1 || s->ctx->generic_level == 2;

@@ -1,0 +1,15 @@
+set -e
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/final
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/final/gpu_tests.txt 2>&1; tail -2 gpurun_out/final/gpu_tests.txt
+python bench.py > gpurun_out/final/bench_line.json 2> gpurun_out/final/bench.err
+python bench.py --workload config2_1e5x64_6+2 --no-cpu-baseline > gpurun_out/final/config2_bench_line.json 2> gpurun_out/final/config2.err
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final/stats -o r02 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --restarts 8 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/final/stats.log 2>&1)
+echo stats done
+bash tools/pmc_passes.sh final/pmc
+timeout -k 10 100 tools/rowpass2_probe 20 2 > gpurun_out/final/rowpass2_probe.txt 2>&1
+timeout -k 10 100 tools/gram_i8_probe > gpurun_out/final/gram_i8_probe.txt 2>&1
+timeout -k 10 100 tools/gram_i8_probe_ns >> gpurun_out/final/gram_i8_probe.txt 2>&1
+timeout -k 10 600 python tools/bootstrap_headline_bench.py 40 20 2>&1 | grep -v amdgpu.ids > gpurun_out/final/bootstrap_headline.txt
+timeout -k 10 200 python tools/restart_overheads.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/restart_overheads.txt
+du -sh gpurun_out/final
