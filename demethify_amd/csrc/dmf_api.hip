@@ -57,6 +57,8 @@ struct dmf_context {
                             // 3 separate MFMA row pass + one-pass Gram (the pieces the fused kernel is made of)
     double* scratch = nullptr;  // 4096 doubles of reduction scratch
     hipMemPool_t pool = nullptr;  // the context's own stream-ordered pool (the device's default pool is not touched)
+    std::vector<void*> pinned_states;   // page-locked SolverState mirrors of destroyed solvers, reused by the next ones
+                                        // (hipHostMalloc / hipHostFree cost ~0.1 ms each: a restart loop makes one per restart)
     hipStream_t copy_stream = nullptr;  // dmf_stage_upload: uploads beside the kernels of `stream` (created on first use)
     std::mutex copy_mutex;
     FamilyClock clocks[DMF_KERNEL_FAMILIES];
@@ -606,6 +608,7 @@ int dmf_context_destroy(dmf_context* ctx) {
         for (auto ev : c.stop) hipEventDestroy(ev);
     }
     hipFree(ctx->scratch);
+    for (void* h : ctx->pinned_states) (void)hipHostFree(h);
     if (ctx->copy_stream != nullptr) {
         hipStreamSynchronize(ctx->copy_stream);
         hipStreamDestroy(ctx->copy_stream);
@@ -914,7 +917,14 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
         if (e == hipSuccess) e = hipMemsetAsync(s->acc_i8, 0, bytes, ctx->stream);
     }
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->state, sizeof(SolverState));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_state, sizeof(SolverState));
+    if (e == hipSuccess) {
+        if (!ctx->pinned_states.empty()) {
+            s->h_state = (SolverState*)ctx->pinned_states.back();
+            ctx->pinned_states.pop_back();
+        } else {
+            e = hipHostMalloc((void**)&s->h_state, sizeof(SolverState));
+        }
+    }
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->job_k, s->n_jobs * sizeof(short));
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->job_l, s->n_jobs * sizeof(short));
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->job_dst, s->n_jobs * sizeof(int));
@@ -956,13 +966,16 @@ int dmf_solver_step(dmf_solver* s, int64_t n_outer, int64_t n_iter2, double tol,
     DMF_TRY(fetch_state(s));
     // The device freezes the iterate once the stop test fires (every kernel checks state->done),
     // so the host may run ahead by `check_every` enqueued iterations without overshooting.
-    const int64_t check_every = s->u_path != 2 ? 8 : 1;
+    // The batches double (8, 16, 32, 64): a solve that runs for hundreds of iterations reads the state back a handful of
+    // times, and what a late stop costs is a few dozen no-op launches.
+    int64_t check_every = s->u_path != 2 ? 8 : 1;
     int64_t enqueued = 0;
     while (enqueued < n_outer && !s->h_state->done) {
         int64_t batch = n_outer - enqueued < check_every ? n_outer - enqueued : check_every;
         for (int64_t b = 0; b < batch; ++b) DMF_TRY(enqueue_outer_iteration(s, (int)n_iter2));
         enqueued += batch;
         DMF_TRY(fetch_state(s));
+        if (s->u_path != 2 && check_every < 64) check_every *= 2;
     }
     if (iters_done_total) *iters_done_total = s->h_state->iters;
     if (converged) *converged = s->h_state->done;
@@ -1030,7 +1043,7 @@ int dmf_solver_destroy(dmf_solver* s) {
     pool_free(ctx, s->u2_partials);
     pool_free(ctx, s->purity);
     pool_free(ctx, s->state);
-    if (s->h_state) hipHostFree(s->h_state);
+    if (s->h_state) ctx->pinned_states.push_back(s->h_state);
     pool_free(ctx, s->job_k);
     pool_free(ctx, s->job_l);
     pool_free(ctx, s->job_dst);

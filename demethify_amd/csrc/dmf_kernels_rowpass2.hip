@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             *reinterpret_cast<v2d*>(tileV + (2 * i + ld_row) * kRowV + ld_col) = pv[i];
+#ifndef DMF_ABLATE_DSTORE
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float* __restrict__ dst = tileD + (8 * i + d_row) * kRowD + d_col;
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
             *reinterpret_cast<v2u*>(bdst + 16 * kRowB) = v2u{__builtin_amdgcn_perm(e1, e0, 0x07050301u),
                                                              __builtin_amdgcn_perm(e3, e2, 0x07050301u)};
         }
+#endif
         double rtop[NKC > 0 ? NKC : 1];
 #pragma unroll
         for (int kc = 0; kc < NKC; ++kc) rtop[kc] = nrt[kc];  // B operand of the first product: Rt^T[k = 4 kc + q][n = row]
@@ -331,6 +333,9 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
             }
             return en;
         };
+#ifdef DMF_ABLATE_E
+        const double csm = tileV[m16 * kRowV + 4 * q];
+#else
         Strip sa, sb;
         load_strip(0, sa);
         load_strip(1, sb);
@@ -347,10 +352,12 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
         const v4d e3 = run_strip(sa, e2, sb, a1r[3], a2r[2], true);
         (void)run_strip(sb, e3, sb, a1r[3], a2r[3], false);
         const double csm = csm0 + csm1;
+#endif
         // M on the integer matrix cores: digit weights 256^0 .. 256^7 (count digit d + P digit t -> weight t + d)
         v4i mw[8];
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8) mw[w8] = v4i{0, 0, 0, 0};
+#ifndef DMF_ABLATE_M  // (diagnostic builds of tools/rowpass2_probe.hip leave pieces out to see what they cost)
         {
             const v4i c0 = *reinterpret_cast<const v4i*>(tileB + m16 * kRowB + 16 * q);  // A: counts [row m16][16 samples]
 #pragma unroll
@@ -361,15 +368,21 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
                 for (int t = 0; t < 7; ++t) mw[t + 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(c1, pdg[t], mw[t + 1], 0, 0, 0);
             }
         }
+#endif
         // lane (pair m16, q) holds rows 4 q + reg: the exact integer sum_w 256^w mw[w] in two halves that fit a double
         // without rounding (|mw| < 2^21 per digit product sum), one rounding when they are joined
         double mrow[4];
+#ifdef DMF_ABLATE_M
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) mrow[rr] = 0.25 * (rr == (m16 & 3));
+#else
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const double lo = fma(fma(fma((double)mw[3][rr], 256.0, (double)mw[2][rr]), 256.0, (double)mw[1][rr]), 256.0, (double)mw[0][rr]);
             const double hi = fma(fma(fma((double)mw[7][rr], 256.0, (double)mw[6][rr]), 256.0, (double)mw[5][rr]), 256.0, (double)mw[4][rr]);
             mrow[rr] = fma(hi, 0x1p32, lo) * 0x1p-52;
         }
+#endif
         DMF2_STAMP(1)  // phase A
         // the next block's global loads: their staging registers were free during phase A, and the loads have
         // phases B and C (and the other workgroups' turns on this CU) to land
@@ -444,6 +457,7 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
         // tools/mfma_probe.hip).  Lane (q, m16) therefore reads (d v) of row 4 R + q, sample 16 t + m16 and u of row
         // 4 R + q, unknown m16 & 3; the 32 tile reads of the block are independent and go out in two batches (a lane =
         // sample loop with per-row broadcast reads of u spent ~1.6k cycles per block on LDS round trips).
+#ifndef DMF_ABLATE_C
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             double vv[2][4], ua[2];
@@ -464,6 +478,7 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
                 for (int t = 0; t < 4; ++t)
                     bu[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ua[rr], (double)dd[rr][t] * vv[rr][t], bu[t], 0, 0, 0);
         }
+#endif
         __builtin_amdgcn_s_setprio(0);
         DMF2_STAMP(6)  // phase C
         // (the next iteration's tile store touches this wave's own tile only; ubuf and red are rewritten behind

@@ -76,10 +76,49 @@ def broadcast_arrays(arrays, src: int):
 
     out = []
     for a in arrays:
-        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        if rank == src:
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        else:  # (the receivers' buffers are allocated where the collective runs: nothing to upload)
+            t = torch.empty(tuple(np.shape(a)), dtype=torch.float64, device=dev)
         dist.broadcast(t, src=src)
         out.append(t.cpu().numpy())
     return tuple(out)
+
+
+def broadcast_winner(solver, u_shape, alpha_shape, owner: int, host_ranks=(0,)):
+    """The winning restart's iterate from the rank that holds its solver to every rank.  One rank: the solver's
+    iterate as host arrays.  More: the profiles leave the owner's solver device to device (Solver.copy_u_to), travel
+    as CUDA tensors (RCCL broadcast, no host staging on any rank) and only the ranks in ``host_ranks`` -- the writer of
+    the output files -- copy them to the host; the others return (None, None).  ``solver`` is None on non-owners."""
+    rank, world, dev = dist_state()
+    if world == 1:
+        u, alpha, _, _ = solver.get()
+        return u, alpha
+    import torch
+    import torch.distributed as dist
+
+    if dev is None or dev.type != "cuda":  # gloo (CPU tests, the one-GPU rehearsal): host arrays
+        payload = ((lambda g: (g[0], g[1]))(solver.get()) if rank == owner
+                   else (np.empty(u_shape), np.empty(alpha_shape)))
+        return broadcast_arrays(payload, owner)
+    return _broadcast_winner_device(solver, u_shape, alpha_shape, owner, rank, dev, host_ranks)
+
+
+def _broadcast_winner_device(solver, u_shape, alpha_shape, owner, rank, dev, host_ranks):
+    import torch
+    import torch.distributed as dist
+
+    u_t = torch.empty(u_shape, dtype=torch.float64, device=dev)
+    a_t = torch.empty(alpha_shape, dtype=torch.float64, device=dev)
+    if rank == owner:
+        solver.copy_u_to(u_t)  # (synchronous on the solver's stream)
+        a_t.copy_(torch.from_numpy(solver.get_alpha()))
+    dist.broadcast(u_t, src=owner)
+    dist.broadcast(a_t, src=owner)
+    if rank in host_ranks:
+        return u_t.cpu().numpy(), a_t.cpu().numpy()
+    torch.cuda.current_stream().synchronize()
+    return None, None
 
 
 def gather_objects(local, root_only=False):

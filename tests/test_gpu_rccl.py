@@ -62,6 +62,23 @@ sys.path.insert(0, os.environ["DMF_ROOT"])
 from demethify_amd import shard
 assert shard.dist_state()[:2] == (0, 1) and shard.dist_state()[2].type == "cuda"
 assert shard.allreduce_min_vector({0: 2.0, 1: 1.0}, 2).tolist() == [2.0, 1.0]
+
+# shard.broadcast_winner's device path (bench.py, N > 1): the iterate leaves the owner's solver as a CUDA tensor,
+# is broadcast in HBM and lands on the host on rank 0 only
+from oracle import solver as osol
+from demethify_amd import _lib as L
+from demethify_amd.device import Context, Problem, Solver
+V, D, Rt = osol.synthetic_problem(640, 32, 4, 2, seed=23, depth=40)
+rs = np.random.RandomState(1)
+u0, a0 = rs.uniform(size=(640, 2)), rs.dirichlet(np.ones(6), 32).T.copy()
+ctx = Context(0)
+with Problem(ctx, V, D, Rt) as p, Solver(p, u0, a0, L.DMF_MODE_PARTIAL) as s:
+    s.step(3, 20, 0.0)
+    want_u, want_a, _, _ = s.get()
+    got_u, got_a = shard._broadcast_winner_device(s, (640, 2), (6, 32), 0, 0, dev, (0,))
+    assert np.array_equal(got_u, want_u) and np.array_equal(got_a, want_a)
+    assert shard._broadcast_winner_device(s, (640, 2), (6, 32), 0, 0, dev, ()) == (None, None)
+ctx.close()
 dist.destroy_process_group()
 print("RCCL_OK")
 """

@@ -66,6 +66,13 @@ def _worker(rank, world, port, out_dir):
     payload = (np.full((3, 2), 5.0),) if rank == 1 else (np.empty((3, 2)),)
     (got,) = shard.broadcast_arrays(payload, 1)
     assert np.array_equal(got, np.full((3, 2), 5.0))
+    # 4b. the winner's iterate from the rank that holds its solver (host path of broadcast_winner: gloo has no device)
+    class _Held:
+        def get(self):
+            return np.full((6, 2), 3.5), np.full((4, 5), 0.25), 1.0, 7
+
+    wu, wa = shard.broadcast_winner(_Held() if rank == 1 else None, (6, 2), (4, 5), 1)
+    assert np.array_equal(wu, np.full((6, 2), 3.5)) and np.array_equal(wa, np.full((4, 5), 0.25))
     # 5. bootstrap post-processing: the stack sharded by replicate is re-partitioned by position range with one
     #    all-to-all; numpy stands in for the HIP percentile kernel here (no GPU in this suite)
     full = np.random.RandomState(3).uniform(size=(7, 37))  # 7 replicates over 2 ranks: 4 + 3; 37 positions: 19 + 18
