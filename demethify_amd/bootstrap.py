@@ -11,8 +11,6 @@ re-partitioned by CpG range with one all-to-all.
 from __future__ import annotations
 
 import os
-import queue
-import threading
 
 import numpy as np
 import pandas as pd
@@ -82,51 +80,61 @@ def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, 
                                     for k in range(n_samples)], axis=1)
             local.append((i, (None, props)))
     else:
-        # Replicate i + 1's host work (MT19937 index draw of N rows, uniform N x n_u + Dirichlet init: tens of
-        # milliseconds at 1e6 rows) is drawn by a worker thread while the GPU solves replicate i.  Each replicate has
-        # its own RandomState(seed_i) for the rows (what sklearn's resample does) and the init re-seeds numpy's global
-        # stream with seed_i (deconvolution.py:41), so the draws do not depend on the order the threads run in; only the
-        # worker touches the global stream while the loop is active.
+        # The host work of the replicates ahead (MT19937 index draw of N rows; uniform N x n_u + Dirichlet init: ~10 + ~13 ms
+        # at 1e6 rows) runs on worker threads while the GPU gathers and solves replicate i.  The row draw has its own
+        # RandomState(seed_i) (what sklearn's resample does); the init re-seeds numpy's GLOBAL stream with seed_i
+        # (deconvolution.py:41), so the draws do not depend on the order the threads run in -- but only ONE thread may
+        # run initialisers at a time.  When the init does not look at the resampled data ('uniform_' and the other
+        # data-free options) the two draws are independent and get a thread each; otherwise one thread does both.
+        from .staging import Prefetcher, reserve, to_device
+
+        ctx = get_context()
+        reserve(((n_rows, n_u), (n_ct + n_u, n_samples)), count=2)
+
         mine = shard.my_items(n_bootstrap, rank, world)
-        feed: queue.Queue = queue.Queue(maxsize=2)
+        needs_data = init_option == "uniform"
 
-        def draw():
-            try:
-                for i in mine:
-                    idx = bootstrap_row_indices(seeds[i], n_rows)
-                    needs_data = init_option == "uniform"
-                    mf = meth_f[idx] if needs_data else np.broadcast_to(meth_f[:1], meth_f.shape)
-                    ct = counts[idx] if needs_data else np.broadcast_to(counts[:1], counts.shape)
-                    rf = ref[idx] if needs_data else np.broadcast_to(ref[:1], ref.shape)
-                    if purity_frac is not None:
-                        u0, _, a0 = init_BSSMF_md_p(init_option, mf, ct, rf, n_u, purity_frac, seed=seeds[i],
-                                                    rb_alg=wls_intercept)
-                    else:
-                        u0, _, a0 = init_BSSMF_md(init_option, mf, ct, rf, n_u, rb_alg=wls_intercept, seed=seeds[i])
-                    feed.put((i, idx, u0, a0))
-            except BaseException as exc:  # hand the failure to the consumer instead of dying silently
-                feed.put(exc)
+        def draw_init(i, idx=None):
+            mf = meth_f[idx] if needs_data else np.broadcast_to(meth_f[:1], meth_f.shape)
+            ct = counts[idx] if needs_data else np.broadcast_to(counts[:1], counts.shape)
+            rf = ref[idx] if needs_data else np.broadcast_to(ref[:1], ref.shape)
+            if purity_frac is not None:
+                u0, _, a0 = init_BSSMF_md_p(init_option, mf, ct, rf, n_u, purity_frac, seed=seeds[i], rb_alg=wls_intercept, _stack=False)
+            else:
+                u0, _, a0 = init_BSSMF_md(init_option, mf, ct, rf, n_u, rb_alg=wls_intercept, seed=seeds[i], _stack=False)
+            return to_device((u0, a0), ctx)  # page-locked copy + upload on the context's copy stream, here in the worker
 
-        worker = threading.Thread(target=draw, daemon=True)
+        def draw_both(i):
+            idx = bootstrap_row_indices(seeds[i], n_rows)
+            return (idx,) + draw_init(i, idx)
+
+        if needs_data:
+            feeds = (Prefetcher(mine, draw_both, depth=2, workers=1),)
+        else:
+            feeds = (Prefetcher(mine, lambda i: bootstrap_row_indices(seeds[i], n_rows), depth=2, workers=1),
+                     Prefetcher(mine, draw_init, depth=2, workers=1))
         u_stack = _device_stack(len(mine), n_rows * n_u)  # replicate profiles stay in HBM when torch is there
-        with Problem(get_context(), meth_f, counts, ref) as full:
-            worker.start()
-            for j in range(len(mine)):
-                item = feed.get()
-                if isinstance(item, BaseException):
-                    raise item
-                i, idx, u0, a0 = item
-                with full.gather(idx) as resampled, Solver(resampled, u0, a0, L.DMF_MODE_PARTIAL) as s:
-                    if purity_frac is not None:
-                        s.set_purity(purity_frac)
-                    s.step(n_iter1, n_iter2, tol)
-                    if u_stack is not None:
-                        s.copy_u_to(u_stack[j])
-                        local.append((i, (None, s.get_alpha())))
+        try:
+            with Problem(ctx, meth_f, counts, ref) as full:
+                for j, parts in enumerate(zip(*feeds)):
+                    if needs_data:
+                        (i, (idx, u0, a0)), = parts
                     else:
-                        u, alpha, _, _ = s.get()
-                        local.append((i, (u, alpha)))
-            worker.join()
+                        (i, idx), (i2, (u0, a0)) = parts
+                        assert i == i2
+                    with full.gather(idx) as resampled, Solver(resampled, u0, a0, L.DMF_MODE_PARTIAL) as s:
+                        if purity_frac is not None:
+                            s.set_purity(purity_frac)
+                        s.step(n_iter1, n_iter2, tol)
+                        if u_stack is not None:
+                            s.copy_u_to(u_stack[j])
+                            local.append((i, (None, s.get_alpha())))
+                        else:
+                            u, alpha, _, _ = s.get()
+                            local.append((i, (u, alpha)))
+        finally:
+            for f in feeds:
+                f.close()
     # proportions (K x S per replicate, KB-sized) go to every rank
     merged = shard.gather_objects([(i, pa) for i, (_, pa) in local])
     props_stack = np.stack([pa for _, pa in merged])  # (B, K, S)

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/demethify_hip.h"
@@ -57,6 +58,9 @@ struct dmf_context {
                             // 3 separate MFMA row pass + one-pass Gram (the pieces the fused kernel is made of)
     double* scratch = nullptr;  // 4096 doubles of reduction scratch
     hipMemPool_t pool = nullptr;  // the context's own stream-ordered pool (the device's default pool is not touched)
+    std::unordered_map<void*, size_t> live;                // large blocks handed out by pool_alloc (size by address)
+    std::unordered_map<size_t, std::vector<void*>> kept;    // freed large blocks kept for the next allocation of that size
+    size_t kept_bytes = 0;
     std::vector<void*> pinned_states;   // page-locked SolverState mirrors of destroyed solvers, reused by the next ones
                                         // (hipHostMalloc / hipHostFree cost ~0.1 ms each: a restart loop makes one per restart)
     hipStream_t copy_stream = nullptr;  // dmf_stage_upload: uploads beside the kernels of `stream` (created on first use)
@@ -170,18 +174,57 @@ static bool pool_enabled() {  // DEMETHIFY_NO_POOL=1: plain hipMalloc / hipFree 
     }();
     return on;
 }
+// Above the pool: freed blocks of 1 MB and more are kept by exact size and handed to the next allocation of that size
+// (a bootstrap replicate frees and re-allocates the same seven multi-GB buffers; hipFreeAsync + hipMallocFromPoolAsync
+// cost ~0.2 ms per large block even when the pool keeps the memory).  Everything that touches these blocks is enqueued
+// on the context's one stream, so a block can be reused the moment it is "freed".  At most kKeepPerSize blocks per size
+// and kKeepBytes in total are kept; the rest goes back to the pool.
+constexpr size_t kKeepMinBytes = (size_t)1 << 20, kKeepBytes = (size_t)24 << 30;
+constexpr int kKeepPerSize = 3;
 static hipError_t pool_alloc(dmf_context* ctx, void** p, size_t bytes) {
     if (!pool_enabled() || ctx->pool == nullptr) return hipMalloc(p, bytes);
-    return hipMallocFromPoolAsync(p, bytes, ctx->pool, ctx->stream);
+    if (bytes >= kKeepMinBytes) {
+        auto it = ctx->kept.find(bytes);
+        if (it != ctx->kept.end() && !it->second.empty()) {
+            *p = it->second.back();
+            it->second.pop_back();
+            ctx->kept_bytes -= bytes;
+            ctx->live[*p] = bytes;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMallocFromPoolAsync(p, bytes, ctx->pool, ctx->stream);
+    if (e != hipSuccess && ctx->kept_bytes > 0) {  // out of memory with blocks parked here: give them back, try again
+        (void)hipGetLastError();
+        for (auto& kv : ctx->kept)
+            for (void* q : kv.second) (void)hipFreeAsync(q, ctx->stream);
+        ctx->kept.clear();
+        ctx->kept_bytes = 0;
+        (void)hipStreamSynchronize(ctx->stream);
+        e = hipMallocFromPoolAsync(p, bytes, ctx->pool, ctx->stream);
+    }
+    if (e == hipSuccess && bytes >= kKeepMinBytes) ctx->live[*p] = bytes;
+    return e;
 }
 static void pool_free(dmf_context* ctx, void* p) {
     if (p == nullptr) return;
     if (!pool_enabled() || ctx->pool == nullptr) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(p);
-    } else {
-        (void)hipFreeAsync(p, ctx->stream);
+        return;
     }
+    auto it = ctx->live.find(p);
+    if (it != ctx->live.end()) {
+        const size_t bytes = it->second;
+        ctx->live.erase(it);
+        auto& slot = ctx->kept[bytes];
+        if ((int)slot.size() < kKeepPerSize && ctx->kept_bytes + bytes <= kKeepBytes) {
+            slot.push_back(p);
+            ctx->kept_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFreeAsync(p, ctx->stream);
 }
 
 int import_array(dmf_context* ctx, const void* src, size_t bytes, int flags, void** dst, bool* owned) {
@@ -308,7 +351,12 @@ int problem_finalize(dmf_problem* p) {
         if (e == hipSuccess)
             e = dmf::launch_gram_reduce(slab, ny, n_fast, (int)S, dd, p->gb_known, nullptr, ctx->stream);
     }
-    if (e == hipSuccess) {
+    if (e == hipSuccess && n_jobs - n_fast == 1 && ctx->generic_level != 1 && ctx->generic_level != 2 &&
+        (int64_t)dmf::vdv_cols_grid(N) * S <= slab_doubles) {
+        // what is left is v^T D v alone: a stream kernel of its own (the generic kernel took 2.7 ms for it at 1e6 x 256)
+        e = dmf::launch_vdv_cols(p->V, p->D, p->D16, p->SD, N, (int)S, slab, p->gb_known + (int64_t)hd[n_jobs - 1] * S,
+                                 ctx->stream);
+    } else if (e == hipSuccess) {
         dmf::GramJobTable rest{dk + n_fast, dl + n_fast, dd + n_fast, n_jobs - n_fast};
         e = dmf::launch_gram(p->V, p->D, p->Rt, nullptr, N, (int)S, (int)n_c, 0, rest, slab, slab_doubles,
                              p->gb_known, nullptr, ctx->stream);
@@ -608,6 +656,10 @@ int dmf_context_destroy(dmf_context* ctx) {
         for (auto ev : c.stop) hipEventDestroy(ev);
     }
     hipFree(ctx->scratch);
+    for (auto& kv : ctx->kept)
+        for (void* q : kv.second) (void)hipFreeAsync(q, ctx->stream);
+    ctx->kept.clear();
+    (void)hipStreamSynchronize(ctx->stream);
     for (void* h : ctx->pinned_states) (void)hipHostFree(h);
     if (ctx->copy_stream != nullptr) {
         hipStreamSynchronize(ctx->copy_stream);

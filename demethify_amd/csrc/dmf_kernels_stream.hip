@@ -333,6 +333,67 @@ __global__ __launch_bounds__(256) void k_cost_cols2(const double* __restrict__ V
     if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
 }
 
+// v^T D v per sample column (the constant term of the Gram-form cost, one entry of the packed Gram's known block):
+// gb[s] = sum_i d_is v_is^2.  Lane = sample, eight rows in flight per wave, workgroup partials summed in workgroup order
+// by the last launch.  The generic Gram kernel spent 2.7 ms on this one job at the headline shape (every bootstrap
+// replicate builds a problem); this stream takes the time of one read of V and the counts.
+template <bool D16>
+__global__ __launch_bounds__(256) void k_vdv_cols(const double* __restrict__ V, const void* __restrict__ Dv, int SD, int64_t N,
+                                                  int S, double* __restrict__ slab) {
+    constexpr int kRows = 8;
+    __shared__ double red[3][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int s = blockIdx.y * 64 + lane;
+    const bool active = s < S;
+    const int sc = active ? s : S - 1;
+    const double* __restrict__ Df = reinterpret_cast<const double*>(Dv);
+    const unsigned short* __restrict__ Dh = reinterpret_cast<const unsigned short*>(Dv);
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t i0 = (int64_t)blockIdx.x * 4 + wave; i0 < N; i0 += kRows * stride) {
+        double v[kRows], d[kRows];
+#pragma unroll
+        for (int x = 0; x < kRows; ++x) {
+            const int64_t i = i0 + x * stride;
+            const int64_t row = i < N ? i : N - 1;
+            v[x] = V[row * S + sc];
+            if constexpr (D16) d[x] = (double)Dh[row * SD + sc];
+            else d[x] = Df[row * S + sc];
+            if (i >= N) d[x] = 0.0;
+        }
+#pragma unroll
+        for (int x = 0; x < kRows; ++x) acc = fma(d[x] * v[x], v[x], acc);
+    }
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && active) slab[(int64_t)blockIdx.x * S + s] = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];
+}
+
+__global__ __launch_bounds__(64) void k_vdv_finish(const double* __restrict__ slab, int nb, int S, double* __restrict__ out) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= S) return;
+    double acc = 0.0;
+    for (int b = 0; b < nb; ++b) acc += slab[(int64_t)b * S + s];
+    out[s] = acc;
+}
+
+int vdv_cols_grid(int64_t N) {
+    int64_t want = (N + 4 * 8 - 1) / (4 * 8);
+    if (want > 256) want = 256;
+    return (int)(want < 1 ? 1 : want);
+}
+
+// slab: vdv_cols_grid(N) * S doubles
+hipError_t launch_vdv_cols(const double* V, const double* D, const unsigned short* D16, int SD, int64_t N, int S, double* slab,
+                           double* out, hipStream_t st) {
+    const int nbx = vdv_cols_grid(N);
+    const dim3 grid(nbx, (S + 63) / 64);
+    if (D16 != nullptr) hipLaunchKernelGGL((k_vdv_cols<true>), grid, dim3(256), 0, st, V, (const void*)D16, SD, N, S, slab);
+    else hipLaunchKernelGGL((k_vdv_cols<false>), grid, dim3(256), 0, st, V, (const void*)D, S, N, S, slab);
+    hipLaunchKernelGGL(k_vdv_finish, dim3((S + 63) / 64), dim3(64), 0, st, slab, nbx, S, out);
+    return hipGetLastError();
+}
+
 bool cost_cols_supported(int S, int n_c, int n_u) { return n_c <= 16 && n_u >= 0 && n_u <= 4 && n_c + n_u >= 1; }
 
 template <int NKC, int NU>

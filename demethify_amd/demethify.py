@@ -201,9 +201,9 @@ def main(argv=None):
                     u0, a0 = _init_unsupervised(args.init, meth_f, n_u, seed_k)
                 elif purity is not None:
                     u0, _, a0 = init_BSSMF_md_p(args.init, meth_f, counts, ref, n_u, purity, rb_alg=wls_intercept,
-                                                seed=seed_k)
+                                                seed=seed_k, _stack=False)
                 else:
-                    u0, _, a0 = init_BSSMF_md(args.init, meth_f, counts, ref, n_u, rb_alg=wls_intercept, seed=seed_k)
+                    u0, _, a0 = init_BSSMF_md(args.init, meth_f, counts, ref, n_u, rb_alg=wls_intercept, seed=seed_k, _stack=False)
                 if args.restart > 1:
                     return staging.to_device((u0, a0), problem.ctx)
                 return u0, a0

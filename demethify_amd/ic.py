@@ -57,7 +57,7 @@ def compute_ccc(alpha_runs):
 
 def _solve(problem, meth_f, counts, ref, n_u, init_option, seed, iter1, iter2, tol):
     if ref is not None:
-        u0, _, a0 = init_BSSMF_md(init_option, meth_f, counts, ref, n_u, seed=seed, rb_alg=wls_intercept)
+        u0, _, a0 = init_BSSMF_md(init_option, meth_f, counts, ref, n_u, seed=seed, rb_alg=wls_intercept, _stack=False)
         mode = L.DMF_MODE_PARTIAL
     else:
         u0, a0 = _init_unsupervised(init_option, meth_f, n_u, seed)
