@@ -260,34 +260,45 @@ int export_array(dmf_context* ctx, const void* dev_src, size_t bytes, int flags,
 }
 
 // Builds the per-problem constants: max(D)^2, ||Rt||_F^2 and the known block of the packed Gram.
-int problem_finalize(dmf_problem* p) {
+// `counts_done`: a row-resampled copy (dmf_problem_gather) whose integer count copies are already gathered from the
+// source's and whose count constants -- max(D) in h_consts[2] and [4], the exactness flags copied -- are set by the
+// caller: the three scans of D and the rebuild of the integer copies are skipped.
+int problem_finalize(dmf_problem* p, bool counts_done = false) {
     dmf_context* ctx = p->ctx;
     const int64_t N = p->N, S = p->S, n_c = p->n_c;
     HIP_TRY(pool_alloc(ctx, (void**)&p->consts, 6 * sizeof(double)));
-    HIP_TRY(dmf::launch_max_f64(p->D, N * S, ctx->scratch, p->consts + 2, ctx->stream));
+    if (!counts_done) HIP_TRY(dmf::launch_max_f64(p->D, N * S, ctx->scratch, p->consts + 2, ctx->stream));
     if (n_c > 0) {
         HIP_TRY(dmf::launch_sumsq_f64(p->Rt, N * n_c, ctx->scratch + 1024, p->consts + 1, nullptr, ctx->stream));
     } else {
         HIP_TRY(hipMemsetAsync(p->consts + 1, 0, sizeof(double), ctx->stream));
     }
-    HIP_TRY(dmf::launch_f32_residual_max(p->D, N * S, ctx->scratch + 2048, p->consts + 3, ctx->stream));
-    HIP_TRY(dmf::launch_int_count_max(p->D, N * S, ctx->scratch + 3072, p->consts + 4, ctx->stream));
-    if (n_c > 0) {
-        HIP_TRY(dmf::launch_unit_range_check(p->Rt, N * n_c, ctx->scratch, p->consts + 5, ctx->stream));
-    } else {
-        HIP_TRY(hipMemsetAsync(p->consts + 5, 0, sizeof(double), ctx->stream));
+    if (!counts_done) {
+        HIP_TRY(dmf::launch_f32_residual_max(p->D, N * S, ctx->scratch + 2048, p->consts + 3, ctx->stream));
+        HIP_TRY(dmf::launch_int_count_max(p->D, N * S, ctx->scratch + 3072, p->consts + 4, ctx->stream));
+        if (n_c > 0) {
+            HIP_TRY(dmf::launch_unit_range_check(p->Rt, N * n_c, ctx->scratch, p->consts + 5, ctx->stream));
+        } else {
+            HIP_TRY(hipMemsetAsync(p->consts + 5, 0, sizeof(double), ctx->stream));
+        }
     }
-    HIP_TRY(hipMemcpyAsync(p->h_consts, p->consts, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    {
+        double got[6];
+        HIP_TRY(hipMemcpyAsync(got, p->consts, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        p->h_consts[1] = got[1];
+        if (!counts_done)
+            for (int i = 2; i < 6; ++i) p->h_consts[i] = got[i];
+    }
     p->h_consts[0] = p->h_consts[2] * p->h_consts[2];  // d = max(D)**2, deconvolution.py:197
     p->d_f32_exact = p->h_consts[3] == 0.0;
-    HIP_TRY(hipMemcpyAsync(p->consts, p->h_consts, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(p->consts, p->h_consts, 6 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (!std::isfinite(p->h_consts[2]) || !std::isfinite(p->h_consts[1])) return DMF_ERR_NONFINITE;
 
     // integer copies of the counts (u16 row-major for the row pass, 8-bit digit planes for the integer-MFMA Gram)
-    if (ctx->generic_level == 0 && p->h_consts[4] <= 32639.0 && p->h_consts[5] == 0.0 && (S & 1) == 0 && S <= 256 &&
-        n_c <= 16) {
+    if (!counts_done && ctx->generic_level == 0 && p->h_consts[4] <= 32639.0 && p->h_consts[5] == 0.0 && (S & 1) == 0 &&
+        S <= 256 && n_c <= 16) {
         p->ND = p->h_consts[4] <= 127.0 ? 1 : 2;
         p->SD = (int)((S + 63) / 64 * 64);
         p->N16 = (N + 15) / 16 * 16;
@@ -816,10 +827,37 @@ int dmf_problem_gather(dmf_context* ctx, const dmf_problem* src, const int64_t* 
     if (e == hipSuccess) e = dmf::launch_gather_rows(src->V, p->V, d_idx, n_idx, p->S, ctx->stream);
     if (e == hipSuccess) e = dmf::launch_gather_rows(src->D, p->D, d_idx, n_idx, p->S, ctx->stream);
     if (e == hipSuccess && p->n_c > 0) e = dmf::launch_gather_rows(src->Rt, p->Rt, d_idx, n_idx, p->n_c, ctx->stream);
+    // integer counts: the source's u16 copy is gathered too (0.5 GB instead of a rebuild from the 2 GB f64 copy) and the
+    // resampled maximum comes out of the same pass; integrality / range of the counts and of R_trunc carry over from the
+    // source, so none of the scans of problem_finalize has to run again
+    bool counts_done = false;
+    unsigned int* d_max = nullptr;
+    if (e == hipSuccess && src->D16 != nullptr && src->ND > 0 && ctx->generic_level == 0) {
+        p->ND = src->ND;
+        p->SD = src->SD;
+        p->N16 = (n_idx + 15) / 16 * 16;
+        p->plane_stride = ((n_idx + 31) / 32) * (p->SD / 32) * 1024;
+        e = pool_alloc(ctx, (void**)&p->D16, (size_t)p->N16 * p->SD * sizeof(unsigned short));
+        if (e == hipSuccess) e = pool_alloc(ctx, (void**)&p->Dt8, (size_t)p->plane_stride * p->ND);
+        if (e == hipSuccess) e = pool_alloc(ctx, (void**)&d_max, sizeof(unsigned int));
+        if (e == hipSuccess)
+            e = dmf::launch_gather_counts_int(src->D16, d_idx, n_idx, p->SD, p->ND, p->D16, p->N16, p->Dt8, p->plane_stride,
+                                              d_max, ctx->stream);
+        unsigned int h_max = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) {
+            p->h_consts[2] = p->h_consts[4] = (double)h_max;
+            p->h_consts[3] = src->h_consts[3];
+            p->h_consts[5] = src->h_consts[5];
+            counts_done = true;
+        }
+        pool_free(ctx, d_max);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     pool_free(ctx, d_idx);
     if (e != hipSuccess) st = hip_fail(e, "row gather", __LINE__);
-    if (st == DMF_OK) st = problem_finalize(p);
+    if (st == DMF_OK) st = problem_finalize(p, counts_done);
     if (st != DMF_OK) {
         dmf_problem_destroy(p);
         return st;

@@ -169,6 +169,9 @@ int64_t gram_mfma_slab_doubles(int64_t N, int S, int n_jobs);
 // ---- second-generation row pass (dmf_kernels_rowpass2.hip) + integer-matrix-core Gram (dmf_kernels_gram_i8.hip)
 // counts as u16 (D16[N16][SD], zero padded: N16 = N rounded up to 16, SD = S rounded up to 64) and as balanced 8-bit
 // digit planes in the MFMA B layout (Dt8[ND][ceil(N/32)][SD/32][32][32]); ND = 1 (d <= 127) or 2 (d <= 32639)
+hipError_t launch_gather_counts_int(const unsigned short* src16, const long long* idx, int64_t n_idx, int SD, int ND,
+                                    unsigned short* D16, int64_t N16, signed char* Dt8, int64_t plane_stride,
+                                    unsigned int* max_out, hipStream_t st);
 hipError_t launch_build_counts_int(const double* D, int64_t N, int S, int ND, unsigned short* D16, int64_t N16, int SD,
                                    signed char* Dt8, int64_t plane_stride, hipStream_t st);
 bool rowpass_v2_supported(int S, int n_c, int n_u, int n_iter2);
