@@ -69,7 +69,8 @@ def make_inputs_on_device(torch, dev, N, S, n_c, n_u, seed=0):
     g.manual_seed(seed)
     R_d = torch.from_numpy(Rfull).to(dev)
     P = torch.clamp(R_d @ torch.from_numpy(A).to(dev), 0.0, 1.0)
-    D = torch.poisson(torch.full((N, S), 50.0, dtype=torch.float64, device=dev), generator=g) + 1.0
+    depth = float(os.environ.get("DMF_BENCH_DEPTH", "50"))  # (experiments: depth > ~100 makes some count exceed 127 -> two count digits)
+    D = torch.poisson(torch.full((N, S), depth, dtype=torch.float64, device=dev), generator=g) + 1.0
     X = torch.binomial(D, P, generator=g)
     V = (X / D).contiguous()
     Rt = R_d[:, :n_c].contiguous()

@@ -385,7 +385,7 @@ __device__ __forceinline__ unsigned long long dmfg_stamp() {
 //   * digits: wave w converts rows 4 w .. 4 w + 3 of all 64 features (lane = feature), one dword per digit;
 //   * three A tiles: iteration b multiplies block b from operands read at the end of iteration b - 1, converts block
 //     b + 2 and reads the operands of block b + 1.
-template <int XL>
+template <int XL, int ND>
 __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restrict__ Dt8, int64_t plane_stride, int SB,
                                                     const double* __restrict__ Rtp, int nct, const double* __restrict__ u,
                                                     int64_t N, int n_c, int n_u, const short* __restrict__ feat_a,
@@ -397,7 +397,9 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
 #endif
                                                     ) {
     constexpr int MF = 64, MA = kNSL * MF;  // feature slots per digit (lane = feature), rows of the A tile
-    constexpr int kSlotB = 4 * 1024, kSlotX = XL * 4096, kSlot = kSlotB + kSlotX;
+    constexpr int NWT = kNSL + ND - 1;  // digit weights 256^0 .. 256^(NWT-1): count digit d + feature digit t -> t + d
+    constexpr int NDMA = ND > XL ? ND : XL;  // DMA descriptors a lane may need (count waves ND, row waves XL)
+    constexpr int kSlotB = 4 * ND * 1024, kSlotX = XL * 4096, kSlot = kSlotB + kSlotX;  // B: [sample group][plane][1 KB]
     constexpr int kAtile = 2 * MA * 4;  // dwords of one block's A tile [2 (h)][MA][4]
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     char* __restrict__ ring = lds_raw;                                                            // [kRing][kSlot]
@@ -450,29 +452,33 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
     offA += row_first * strideA;
     offB += row_first * strideB;
 
-    v16i acc[kNSL];
+    v16i acc[NWT];
 #pragma unroll
-    for (int a = 0; a < kNSL; ++a)
+    for (int a = 0; a < NWT; ++a)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][e] = 0;
 
-    // One DMA descriptor per lane and piece: source = base + min(block * step, limit).  Waves 0..3 fetch the count tile
-    // of their sample group (one piece), waves 4..7 the XL pieces of the x image: 16-B chunk c of
+    // One DMA descriptor per lane and piece: source = base + min(block * step, limit).  Waves 0..3 fetch the ND count
+    // planes of their sample group, waves 4..7 the XL pieces of the x image: 16-B chunk c of
     // [32 rows of the padded R_trunc copy][32 rows of u]; the limit keeps the last block's chunks inside the arrays
     // (rows of the padded copy are multiples of 32 B; u may end on an odd double, the solver rounds its allocation up).
-    const char* gbase[XL];
-    int64_t glim[XL];
-    int gstep[XL], lds_dst[XL];
+    const char* gbase[NDMA];
+    int64_t glim[NDMA];
+    int gstep[NDMA], lds_dst[NDMA];
+    const int n_dma = wave < 4 ? ND : XL;  // (wave-uniform)
 #pragma unroll
-    for (int x = 0; x < XL; ++x) {
-        if (wave < 4) {
-            gbase[x] = reinterpret_cast<const char*>(Dt8) + (((r_begin >> 5) * SB + sbc) * 1024 + (lane & 31) * 32 + (lane >> 5) * 16);
+    for (int x = 0; x < NDMA; ++x) {
+        if (wave < 4) {  // count planes of this wave's sample group
+            const int xp = x < ND ? x : ND - 1;
+            gbase[x] = reinterpret_cast<const char*>(Dt8) + (int64_t)xp * plane_stride +
+                       (((r_begin >> 5) * SB + sbc) * 1024 + (lane & 31) * 32 + (lane >> 5) * 16);
             gstep[x] = SB * 1024;
             glim[x] = (int64_t)1 << 62;
-            lds_dst[x] = sg * 1024;
+            lds_dst[x] = (sg * ND + xp) * 1024;
         } else {
             const int n_chunk_rt = 16 * nct, n_chunks = 16 * (nct + n_u);
-            int c = (tid - 256) + 256 * x;
+            const int xx = x < XL ? x : XL - 1;
+            int c = (tid - 256) + 256 * xx;
             if (c >= n_chunks) c = n_chunks - 1;  // lands in the slot's padding
             if (c < n_chunk_rt) {
                 const int64_t off0 = r_begin * nct * 8 + (int64_t)c * 16;
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
                 gstep[x] = 32 * n_u * 8;
                 glim[x] = ((N * n_u * 8 - 8) & ~(int64_t)15) - off0;
             }
-            lds_dst[x] = kSlotB + (x * 4 + (wave - 4)) * 1024;
+            lds_dst[x] = kSlotB + (xx * 4 + (wave - 4)) * 1024;
         }
     }
     const bool tail_clamp = r_end == N && (N & 31) != 0;  // only the last block of the last row range can run past N
@@ -493,8 +499,8 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
         const int jc = j < nb ? j : nb - 1;  // beyond the range: a repeat of the last block keeps the DMA count uniform
         char* __restrict__ slot = ring + (j % kRing) * kSlot;
 #pragma unroll
-        for (int x = 0; x < XL; ++x) {
-            if (x > 0 && wave < 4) break;
+        for (int x = 0; x < NDMA; ++x) {
+            if (x >= n_dma) break;
             int64_t off = (int64_t)jc * gstep[x];
             if (tail_clamp && jc == nb - 1) off = off < glim[x] ? off : glim[x];
             __builtin_amdgcn_global_load_lds((gmem_void*)(gbase[x] + off), (lds_int*)(slot + lds_dst[x]), 16, 0, 0);
@@ -530,9 +536,11 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
         transpose4(hi, th);
         store_digits(buf);
     };
-    v4i bq, aop[kNSL];
+    v4i bq[ND], aop[kNSL];
     auto load_operands = [&](int j, int abuf) {
-        bq = *reinterpret_cast<const v4i*>(ring + (j % kRing) * kSlot + sg * 1024 + lane * 16);
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+            bq[d] = *reinterpret_cast<const v4i*>(ring + (j % kRing) * kSlot + (sg * ND + d) * 1024 + lane * 16);
         const unsigned int* __restrict__ at = atile + abuf * kAtile + (((lane >> 5) * MA + 32 * fh + (lane & 31)) << 2);
 #pragma unroll
         for (int t = 0; t < kNSL; ++t) aop[t] = *reinterpret_cast<const v4i*>(at + ((t * MF) << 2));
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
     // registers are never consumed.
     const char* __restrict__ rowA = ring + kSlotB + offA;
     const char* __restrict__ rowB = ring + kSlotB + offB;
-    const char* __restrict__ bsrc = ring + sg * 1024 + lane * 16;
+    const char* __restrict__ bsrc = ring + sg * ND * 1024 + lane * 16;
 #pragma unroll 1
     for (int b0 = 0; b0 < nb; b0 += kRing) {
 #pragma unroll
@@ -572,10 +580,10 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
             const int a_next = a_cur == 2 ? 0 : a_cur + 1, a_gen = a_next == 2 ? 0 : a_next + 1;
             DMFG_STAMP(0)
             // own DMA of blocks <= b + 3 landed, own LDS traffic (digit writes, operand and row reads) done; then
-            // everyone's (waves 0..3 have one DMA per block in flight, waves 4..7 XL)
+            // everyone's (waves 0..3 have ND DMAs per block in flight, waves 4..7 XL)
             // (the DMA of block b + kRing - 1 is issued further down, in the matrix phase: blocks b + 4 .. b + kRing - 2
             // may still be in flight here)
-            if (XL == 1 || wave < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kRing - 5) : "memory");
+            if (XL == ND || wave < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kRing - 5) * ND) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kRing - 5) * XL) : "memory");
             DMFG_STAMP(1)
             __builtin_amdgcn_s_barrier();
@@ -591,19 +599,25 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
             const int row_off = ((uu + 3) & kMask) * kSlot + kRowSlot, op_off = ((uu + 1) & kMask) * kSlot;
 #pragma unroll
             for (int t = 0; t < kNSL; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[t], bq, acc[t], 0, 0, 0);
-                if (t < 4) convert_row(t);
-                else if (t == 4) transpose4(lo, tl);
-                else if (t == 5) transpose4(hi, th);
-                __builtin_amdgcn_sched_barrier(0);
-                aop[t] = *reinterpret_cast<const v4i*>(at_next + ((t * MF) << 2));
-                if (t < 4) {
-                    xa[t] = *reinterpret_cast<const double*>(rowA + t * strideA + row_off);
-                    xv[t] = *reinterpret_cast<const double*>(rowB + t * strideB + row_off);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    acc[t + d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[t], bq[d], acc[t + d], 0, 0, 0);
+                    // (the conversion pieces sit behind the first MFMAs of the block: one per MFMA)
+                    const int slot = t * ND + d;
+                    if (slot < 4) convert_row(slot);
+                    else if (slot == 4) transpose4(lo, tl);
+                    else if (slot == 5) transpose4(hi, th);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (slot < 4) {
+                        xa[slot] = *reinterpret_cast<const double*>(rowA + slot * strideA + row_off);
+                        xv[slot] = *reinterpret_cast<const double*>(rowB + slot * strideB + row_off);
+                    }
+                    if (d == ND - 1) aop[t] = *reinterpret_cast<const v4i*>(at_next + ((t * MF) << 2));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
-            bq = *reinterpret_cast<const v4i*>(bsrc + op_off);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) bq[d] = *reinterpret_cast<const v4i*>(bsrc + d * 1024 + op_off);
             DMFG_STAMP(3)
             {   // DMA of block b + kRing - 1 into the slot of block b - 1 (its count tile and rows went to registers long
                 // ago), here rather than at the head of the iteration: while this wave waits for the load path to take
@@ -611,8 +625,8 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
                 const int j = b + kRing - 1, jc = j < nb ? j : nb - 1;  // beyond the range: a repeat keeps the DMA count uniform
                 char* __restrict__ slot = ring + ((uu + kRing - 1) & kMask) * kSlot;
 #pragma unroll
-                for (int x = 0; x < XL; ++x) {
-                    if (x > 0 && wave < 4) break;
+                for (int x = 0; x < NDMA; ++x) {
+                    if (x >= n_dma) break;
                     int64_t off = (int64_t)jc * gstep[x];
                     if (tail_clamp && jc == nb - 1) off = off < glim[x] ? off : glim[x];
                     __builtin_amdgcn_global_load_lds((gmem_void*)(gbase[x] + off), (lds_int*)(slot + lds_dst[x]), 16, 0, 0);
@@ -637,7 +651,7 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
             const int p = 32 * fh + m;
             long long lo = 0, hi = 0;
 #pragma unroll
-            for (int wt = 0; wt < kNSL; ++wt) {
+            for (int wt = 0; wt < NWT; ++wt) {
                 const long long v = (long long)acc[wt][e];
                 if (wt < 4) lo += v << (8 * wt);
                 else hi += v << (8 * (wt - 4));
@@ -890,25 +904,25 @@ size_t gram_i8_lds_bytes(int nft, int nd, int xl) {
     return (size_t)kRing * (4 * nd * 1024 + xl * 4096) + (size_t)2 * 2 * (kNSL * 32 * nft) * 16;
 }
 
-size_t gram_i8_w8_lds_bytes(int xl) { return (size_t)kRing * (4096 + xl * 4096) + (size_t)3 * 2 * (kNSL * 64) * 16; }
+size_t gram_i8_w8_lds_bytes(int xl, int nd) { return (size_t)kRing * (4096 * nd + xl * 4096) + (size_t)3 * 2 * (kNSL * 64) * 16; }
 
-template <int XL>
+template <int XL, int ND>
 static hipError_t launch_gram_i8_w8_t(const signed char* Dt8, int64_t plane_stride, int SD, const double* Rtp, const double* u,
                                       int64_t N, int n_c, int n_u, const short* fa, const short* fb, int NF, int p0, int MFtot,
                                       long long* slab, const int* done_flag, hipStream_t st) {
     int nsh, ny;
     int64_t rpw;
     gram_i8_geometry(N, SD, &nsh, &ny, &rpw);
-    const size_t lds = gram_i8_w8_lds_bytes(XL);
+    const size_t lds = gram_i8_w8_lds_bytes(XL, ND);
     static bool lds_limit_raised[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!lds_limit_raised[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gram_i8_w8<XL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_gram_i8_w8<XL, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_limit_raised[dev] = true;
     }
-    hipLaunchKernelGGL((k_gram_i8_w8<XL>), dim3(nsh * ny), dim3(512), lds, st, Dt8, plane_stride, SD / 32, Rtp,
+    hipLaunchKernelGGL((k_gram_i8_w8<XL, ND>), dim3(nsh * ny), dim3(512), lds, st, Dt8, plane_stride, SD / 32, Rtp,
                        (n_c + 3) / 4 * 4, u, N, n_c, n_u, fa, fb, NF, p0, MFtot, rpw, slab, SD, done_flag
 #ifdef DMF_STAMPS
                        , (unsigned long long*)nullptr
@@ -951,17 +965,22 @@ hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, 
     if ((int64_t)ny * 2 * MFtot * SD > slab_words || rpw * 128 * 128 * ND >= (int64_t)1 << 31) return hipErrorInvalidValue;
     // accumulator registers: (7 + ND - 1) * NFT tiles of 16 per wave -> 64 features per launch with one count digit,
     // 32 with two; more features = more launches over the (small) 8-bit planes
-    const int chunk = ND == 1 ? 64 : 32;
+    // the eight-wave kernel takes 64 features per launch (one count digit; two digits while the block's rows fit one
+    // DMA piece: the LDS does not hold a ring of 16-KB slots), the four-wave kernel 64 / 32
+    const bool wide = (n_c + 3) / 4 * 4 + n_u > 16;  // x image of a block beyond 4 KB: two DMA pieces per thread
+    const bool w8_nd2 = ND == 2 && !wide;
+    const int chunk = (ND == 1 || w8_nd2) ? 64 : 32;
     for (int p0 = 0; p0 < NF; p0 += chunk) {
         const int nf = NF - p0 < chunk ? NF - p0 : chunk;
         hipError_t e;
 #define DMF_GI8(F, D_, X)                                                                                                 \
     e = launch_gram_i8_t<F, D_, X>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st)
-        const bool wide = (n_c + 3) / 4 * 4 + n_u > 16;  // x image of a block beyond 4 KB: two DMA pieces per thread
         if (ND == 1 && nf > 32) {  // the headline shapes: eight waves, two per SIMD
-            if (wide) e = launch_gram_i8_w8_t<2>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
-            else e = launch_gram_i8_w8_t<1>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
+            if (wide) e = launch_gram_i8_w8_t<2, 1>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
+            else e = launch_gram_i8_w8_t<1, 1>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
         }
+        else if (w8_nd2 && nf > 16)  // two count digits (some count above 127: what sequencing data looks like)
+            e = launch_gram_i8_w8_t<1, 2>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
         else if (ND == 1) { if (wide) DMF_GI8(1, 1, 2); else DMF_GI8(1, 1, 1); }
         else { if (wide) DMF_GI8(1, 2, 2); else DMF_GI8(1, 2, 1); }
 #undef DMF_GI8

@@ -89,6 +89,8 @@ V2_CASES = [
     (4096, 256, 12, 4, 3, 60, "eight-wave Gram, 128 row ranges x 2 sample halves: the XCD-aware workgroup order"),
     (8197, 64, 12, 4, 3, 60, "eight-wave Gram, one sample quarter-group per range (nsh = 1), last block 5 rows"),
     (1013, 200, 10, 3, 3, 60, "eight-wave Gram, 36 features (28 lanes idle), ragged samples, natural workgroup order"),
+    (3000, 256, 12, 4, 3, 2500, "eight-wave Gram with two count digits (counts above 127), 58 features in one launch"),
+    (2005, 130, 8, 3, 3, 1500, "eight-wave Gram, two count digits, 30 features, ragged samples, last block 21 rows"),
 ]
 
 
@@ -208,7 +210,8 @@ def test_config5_shape_properties(ctx):
     assert int(np.argmin(scores[0])) == int(np.argmin(scores[3]))
 
 
-@pytest.mark.parametrize("N,S,n_c,n_u,depth", [(1500, 64, 16, 4, 2500), (4096, 256, 12, 4, 60), (20000, 64, 6, 2, 40)])
+@pytest.mark.parametrize("N,S,n_c,n_u,depth", [(1500, 64, 16, 4, 2500), (4096, 256, 12, 4, 60), (20000, 64, 6, 2, 40),
+                                                (4096, 256, 12, 4, 2500)])
 def test_in_launch_hand_overs_are_race_free(ctx, N, S, n_c, n_u, depth):
     """The Gram reduce finishes its own columns in the last workgroup to arrive and the K <= 16 alpha kernel closes the
     outer iteration the same way (atomics-only hand-over, no kernel boundary in between).  The sums involved are exact
