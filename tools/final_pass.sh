@@ -10,6 +10,7 @@ bash tools/pmc_passes.sh final/pmc
 timeout -k 10 100 tools/rowpass2_probe 20 2 > gpurun_out/final/rowpass2_probe.txt 2>&1
 timeout -k 10 100 tools/gram_i8_probe > gpurun_out/final/gram_i8_probe.txt 2>&1
 timeout -k 10 100 tools/gram_i8_probe_ns >> gpurun_out/final/gram_i8_probe.txt 2>&1
-timeout -k 10 600 python tools/bootstrap_headline_bench.py 40 20 2>&1 | grep -v amdgpu.ids > gpurun_out/final/bootstrap_headline.txt
+(timeout -k 10 600 python tools/bootstrap_headline_bench.py 40 20; timeout -k 10 600 python tools/bootstrap_headline_bench.py 120 20; timeout -k 10 300 python tools/replicate_overheads.py | tail -2) 2>&1 | grep -v amdgpu.ids > gpurun_out/final/bootstrap_headline.txt
 timeout -k 10 200 python tools/restart_overheads.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/restart_overheads.txt
 du -sh gpurun_out/final
+DMF_BENCH_DEPTH=120 python bench.py --no-cpu-baseline --restarts 8 > gpurun_out/final/deep_coverage_bench_line.json 2> gpurun_out/final/deep.err
