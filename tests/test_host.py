@@ -256,3 +256,33 @@ def test_interval_csv_writer_is_byte_identical_to_pandas(tmp_path):
     assert _write_interval_csv(str(got), cols, lower, upper)
     assert got.read_bytes() == want.read_bytes()
     assert not _write_interval_csv(str(got), ["a,b", "c", "d"], lower, upper)  # a header that needs quoting: pandas' job
+
+
+def test_prefetcher_with_several_workers_keeps_item_order():
+    """Three workers, results of uneven duration: the consumer still sees the items in order, never more than `depth`
+    ahead, and an exception arrives at its item's position."""
+    import threading
+    import time
+
+    from demethify_amd.staging import Prefetcher
+
+    started, lock = [], threading.Lock()
+
+    def fn(k):
+        with lock:
+            started.append(k)
+        time.sleep(0.02 * ((7 * k) % 3))
+        if k == 9:
+            raise ValueError("item 9")
+        return -k
+
+    pf = Prefetcher(range(12), fn, depth=3, workers=3)
+    seen = []
+    with pytest.raises(ValueError, match="item 9"):
+        for k, r in pf:
+            assert r == -k
+            with lock:
+                assert max(started) <= k + 3  # at most `depth` items beyond the one being consumed
+            seen.append(k)
+    assert seen == list(range(9))
+    pf.close()
