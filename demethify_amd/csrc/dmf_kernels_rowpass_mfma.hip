@@ -14,6 +14,8 @@
 //   A[i][k]: lane (i = l & 15, k = l >> 4);  B[k][j]: lane (k = l >> 4, j = l & 15);
 //   C/D register r of lane l = C[(l >> 4) + 4 r][l & 15].
 // `Rt` here is the problem's padded copy of R_trunc: row stride 4 * NKC doubles, zero pad columns.
+#include <cstdlib>
+
 #include "dmf_device.h"
 #include "dmf_internal.h"
 
@@ -304,7 +306,12 @@ static hipError_t launch_u_mfma_t(const double* V, const double* D, const double
         if (e != hipSuccess) return e;
     }
     const int64_t nblk = (N + 15) / 16;
-    const int64_t grid = nblk < 768 ? nblk : 768;
+    // persistent workgroups: as many as fit two waves per SIMD (the kernel needs ~250 registers) -- 3 per CU at
+    // NW = 2 left a quarter of the wave slots empty
+    int per_cu = NW >= 8 ? 1 : 8 / NW;
+    if (const char* v = getenv("DMF_UMFMA_PER_CU")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (experiments)
+    const int64_t cap = (int64_t)256 * per_cu;
+    const int64_t grid = nblk < cap ? nblk : cap;
     if (vec)
         hipLaunchKernelGGL((k_u_phase_mfma<NKC, NU, true>), dim3((unsigned)grid), dim3(NW * 64), lds, st, V, D, Rt,
                            alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out);
