@@ -409,7 +409,16 @@ int enqueue_u_phase(dmf_solver* s, int n_iter2) {
                                         (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
         return DMF_OK;
     }
-    if (s->u_path == 0 && n_iter2 > kSplitInnerSteps) {
+    // The split form also wins at few inner steps once the row groups are wide: with 7 or 8 unknowns the inner steps
+    // inside k_u_phase_mfma broadcast through ds_bpermute on ONE wave per workgroup and the kernel spills (measured at
+    // 5e5 x 128, 20 steps: 0+8 0.70 -> 0.57 ms, 12+6 0.62 -> 0.48; 0+5 equal, 0+6 0.37 -> 0.39): split from 7 unknowns
+    // on, and from 5 when there are known types (their E product already fills the row kernel).
+    // DMF_SPLIT_NU=n moves the threshold (experiments).
+    static const int split_nu = [] {
+        const char* v = getenv("DMF_SPLIT_NU");
+        return v != nullptr && atoi(v) > 0 ? atoi(v) : 7;
+    }();
+    if (s->u_path == 0 && (n_iter2 > kSplitInnerSteps || (int)s->n_u >= split_nu || (p->n_c > 0 && s->n_u >= 5))) {
         // many inner steps: one wave per workgroup running them is the bottleneck (see enqueue_outer_iteration)
         if (s->cm == nullptr)
             HIP_TRY(pool_alloc(ctx, (void**)&s->cm, (size_t)dmf::u_phase_split_cm_doubles(p->N, (int)s->n_u) * sizeof(double)));
@@ -1165,7 +1174,8 @@ int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t
         snprintf(gram, sizeof(gram), "fused");
     } else {
         if (s->use_u_big && dmf::u_phase_big_supported(S, n_c, n_u, (int)n_iter2)) snprintf(row, sizeof(row), "k_u_phase_big");
-        else if (s->u_path == 0 && n_iter2 > kSplitInnerSteps) snprintf(row, sizeof(row), "k_u_phase_mfma(split)+k_u_inner_rows");
+        else if (s->u_path == 0 && (n_iter2 > kSplitInnerSteps || n_u >= 7 || (n_c > 0 && n_u >= 5)))
+            snprintf(row, sizeof(row), "k_u_phase_mfma(split)+k_u_inner_rows");
         else if (s->u_path == 0) snprintf(row, sizeof(row), "k_u_phase_mfma");
         else if (s->u_path == 1) snprintf(row, sizeof(row), "k_u_phase_gram");
         else snprintf(row, sizeof(row), "k_u_step_direct");
