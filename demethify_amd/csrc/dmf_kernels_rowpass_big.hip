@@ -15,6 +15,8 @@
 // Layouts (tools/mfma_probe.hip): A[i][k]: lane (i = l & 15, k = l >> 4); B[k][j]: lane (k = l >> 4, j = l & 15);
 // C register r of lane l = C[(l >> 4) + 4 r][l & 15]; "row-on-lane": lane = (row = l & 15, q = l >> 4),
 // register r <-> sample s0 + 4 q + r.
+#include <cstdlib>
+
 #include "dmf_device.h"
 #include "dmf_internal.h"
 
@@ -286,7 +288,8 @@ static hipError_t launch_big_t(const double* V, const double* D, const double* R
         raised[dev] = true;
     }
     const int64_t nblk = (N + 15) / 16;
-    const int per_cu = lds <= 78 * 1024 ? 2 : 1;
+    int per_cu = lds <= 78 * 1024 ? 2 : 1;
+    if (const char* v = getenv("DMF_UBIG_PER_CU")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (experiments)
     const int64_t want = 256 * per_cu;
     const int64_t grid = nblk < want ? nblk : want;
     hipLaunchKernelGGL((k_u_phase_big<NKC, GS>), dim3((unsigned)grid), dim3(GS == 16 ? 256 : 512), lds, st, V, D, Rtp,
