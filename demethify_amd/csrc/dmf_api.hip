@@ -297,8 +297,9 @@ int problem_finalize(dmf_problem* p, bool counts_done = false) {
     if (!std::isfinite(p->h_consts[2]) || !std::isfinite(p->h_consts[1])) return DMF_ERR_NONFINITE;
 
     // integer copies of the counts (u16 row-major for the row pass, 8-bit digit planes for the integer-MFMA Gram)
+    // (S <= 1024: the row pass itself stops at 256 samples, the integer Gram, b_u and cost kernels do not)
     if (!counts_done && ctx->generic_level == 0 && p->h_consts[4] <= 32639.0 && p->h_consts[5] == 0.0 && (S & 1) == 0 &&
-        S <= 256 && n_c <= 16) {
+        S <= 1024 && n_c <= 16) {
         p->ND = p->h_consts[4] <= 127.0 ? 1 : 2;
         p->SD = (int)((S + 63) / 64 * 64);
         p->N16 = (N + 15) / 16 * 16;

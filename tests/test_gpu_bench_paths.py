@@ -237,3 +237,20 @@ def test_in_launch_hand_overs_are_race_free(ctx, N, S, n_c, n_u, depth):
                 assert cost == first[2], rep
                 np.testing.assert_array_equal(alpha, first[1], err_msg=f"repetition {rep}")
                 np.testing.assert_array_equal(u, first[0], err_msg=f"repetition {rep}")
+
+
+@pytest.mark.parametrize("N,S,n_c,n_u", [(3000, 320, 12, 4), (2500, 512, 10, 5)])
+def test_beyond_256_samples_integer_gram_behind_the_row_kernels(ctx, N, S, n_c, n_u):
+    """S > 256: the second-generation row pass does not take the shape, but the integer Gram (with the b_u stream kernel)
+    and the u16 cost kernel do -- the u phase runs on the first-generation MFMA kernels."""
+    from demethify_amd import _lib as L
+
+    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=11, depth=40)
+    T1 = 3
+    u0, a0, wu, wa = _oracle(V, D, Rt, n_c, n_u, T1, seed=2)
+    u, alpha, cost, direct, path = _solve_at_level(ctx, 0, V, D, Rt, u0, a0, L.DMF_MODE_PARTIAL, T1,
+                                                   ["rowpass=k_u_phase_mfma", "gram=k_bu_cols+k_gram_i8<nd=1>"])
+    assert rel_err(alpha, wa) < TIGHT and np.abs(alpha - wa).max() < TIGHT
+    assert np.abs(u - wu).max() < TIGHT
+    want = osol.weighted_cost(V, np.c_[Rt, wu], wa, D)
+    assert cost == pytest.approx(want, rel=1e-9) and direct == pytest.approx(want, rel=1e-11)
