@@ -1,0 +1,18 @@
+"""A short randomised differential run (tools/fuzz_parity.py): random small shapes -- ragged sample counts, partial last
+blocks, zero-coverage cells, one and two count digits, 0..16 known and 1..12 unknown types -- through kernel selection
+level 0 against the CPU oracle at 1e-8.  The full campaign (800+ cases per seed) is run by hand when kernels change."""
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_shapes_against_oracle():
+    proc = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz_parity.py"), "90", "7"], cwd=ROOT,
+                          capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0 and "MISMATCH" not in proc.stdout, (proc.stdout[-3000:], proc.stderr[-2000:])
+    assert "90 cases" in proc.stdout
