@@ -77,6 +77,23 @@ class DemethifyHipError(RuntimeError):
         super().__init__(msg)
 
 
+def _preload_torch_hip_runtime():
+    import importlib.util
+    import os
+
+    if os.environ.get("DEMETHIFY_SYSTEM_HIP") == "1":  # (opt out: use the runtime this library was linked against)
+        return
+    try:
+        spec = importlib.util.find_spec("torch")  # (does not import torch)
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+        if cand.exists():
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+    except Exception:  # pragma: no cover - no torch, or a wheel without the bundled runtime: nothing to align
+        pass
+
+
 def load():
     """Load the shared library (once) and type every entry point."""
     global _lib
@@ -98,6 +115,13 @@ def load():
                 torch.cuda.init()
         except Exception:  # pragma: no cover - torch without a usable GPU: our own checks will report it
             pass
+    else:
+        # torch is installed but not imported yet (the CLI): a later `import torch` -- the bootstrap's replicate stack,
+        # torch.distributed -- would bring a SECOND HIP runtime into the process and find no GPU with it (measured: two
+        # libamdhip64 in /proc/self/maps, torch.cuda.is_available() False).  Loading torch's copy of the runtime first
+        # makes it the one this library binds to as well -- the configuration bench.py and the test-suite run in --
+        # without paying for `import torch` (1.5 s) in runs that never need it.
+        _preload_torch_hip_runtime()
     lib = C.CDLL(str(LIB_PATH))
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)
