@@ -414,6 +414,68 @@ __global__ __launch_bounds__(256) void k_u_inner_rows(const double* __restrict__
     }
 }
 
+// The same inner iterations with ONE CpG row per 16-lane DPP row (lane j < NU of the row holds unknown j): the gradient
+// needs lane l's value in every lane of the row, which v_fmac_f64_dpp row_newbcast:l delivers inside the multiply-add --
+// NU instructions per step where the group form above pays 2 NU ds_bpermute round trips (k_u_inner_rows<8>: 239 us at
+// 5e5 rows and 20 steps; this form: see DESIGN.md).  Same per-row arithmetic order: g = c_j - sum_l M_jl x_l, l ascending.
+template <int L>
+__device__ __forceinline__ void fmac_row16(double& acc, double x, double m) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc)
+                 : "v"(x), "v"(m), "n"(L));
+}
+template <int NU, int L = 0>
+__device__ __forceinline__ void grad_row16(double& g, double base, const double (&Mneg)[NU]) {
+    if constexpr (L < NU) {
+        fmac_row16<L>(g, base, Mneg[L]);
+        grad_row16<NU, L + 1>(g, base, Mneg);
+    }
+}
+
+template <int NU>
+__global__ __launch_bounds__(256) void k_u_inner_rows16(const double* __restrict__ cm, const double* __restrict__ beta_g,
+                                                        double* __restrict__ u, double* __restrict__ u_prev,
+                                                        const SolverState* __restrict__ state, int64_t N, int n_iter2,
+                                                        int mode) {
+    static_assert(NU >= 1 && NU <= 16, "one row per DPP row");
+    constexpr int NP = NU * (NU + 1) / 2, NV = NU + NP;
+    extern __shared__ double beta_tab[];
+    if (state->done) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 4 + (lane >> 4);
+    const bool ok = j < NU && row < N;
+    const int64_t rowc = row < N ? row : 0;
+    const int jc = j < NU ? j : 0;
+    const double inv_lw = 1.0 / state->l_w;  // as in k_u_phase_mfma
+    const double* __restrict__ mine = cm + rowc * NV;
+    const double cj = mine[jc];
+    double Mneg[NU];
+#pragma unroll
+    for (int l = 0; l < NU; ++l) Mneg[l] = -mine[NU + (l <= jc ? tri(l, jc) : tri(jc, l))];
+    const int64_t gi = rowc * NU + jc;
+    double uu = ok ? u[gi] : 0.0, up = ok ? u_prev[gi] : 0.0;
+    for (int t0 = 0; t0 < n_iter2; t0 += kBetaChunk) {
+        const int nt = n_iter2 - t0 < kBetaChunk ? n_iter2 - t0 : kBetaChunk;
+        if (t0 > 0) __syncthreads();  // the previous chunk has been consumed by every wave
+        for (int t = threadIdx.x; t < nt; t += 256) beta_tab[t] = beta_g[t0 + t];
+        __syncthreads();
+        for (int t2 = 0; t2 < nt; ++t2) {
+            const double beta = beta_tab[t2];
+            const double ut = uu + beta * (uu - up);
+            const double base = mode == 1 ? uu : ut;  // deconvolution.py:163 vs :88
+            up = uu;
+            double g = cj;
+            grad_row16<NU>(g, base, Mneg);
+            uu = fmin(fmax(fma(g, inv_lw, ut), 0.0), 1.0);
+        }
+    }
+    if (ok) {
+        u[gi] = uu;
+        u_prev[gi] = up;
+    }
+}
+
 int64_t u_phase_split_cm_doubles(int64_t N, int n_u) { return N * (n_u + (int64_t)n_u * (n_u + 1) / 2); }
 
 // cm: N x (n_u + NP) doubles, beta: n_iter2 doubles (both device scratch owned by the caller)
@@ -433,8 +495,15 @@ hipError_t launch_u_phase_split(const double* V, const double* D, const double* 
                            state, N, n_iter2, mode);                                                           \
         break;                                                                                                 \
     }
+#define DMF_CASE16(NU_)                                                                                          \
+    case NU_: {                                                                                                  \
+        const int64_t grid = (N + 15) / 16; /* 4 waves x 4 rows */                                               \
+        hipLaunchKernelGGL((k_u_inner_rows16<NU_>), dim3((unsigned)grid), dim3(256), lds, st, cm, beta, u, u_prev, \
+                           state, N, n_iter2, mode);                                                             \
+        break;                                                                                                   \
+    }
     switch (n_u) {
-        DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4) DMF_CASE(5) DMF_CASE(6) DMF_CASE(7) DMF_CASE(8)
+        DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4) DMF_CASE16(5) DMF_CASE16(6) DMF_CASE16(7) DMF_CASE16(8)
         default: return hipErrorInvalidValue;
     }
 #undef DMF_CASE
