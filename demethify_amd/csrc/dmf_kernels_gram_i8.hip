@@ -595,8 +595,7 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
             // matrix phase and only the seven digit stores remain behind it.  No branches: a wave beyond the last
             // sample block multiplies a repeat tile into accumulators that are never stored.
             const unsigned int* __restrict__ at_next = atile + a_next * kAtile + (((lane >> 5) * MA + 32 * fh + (lane & 31)) << 2);
-            constexpr int kRowSlot = 0;  // (placeholder so that the next two lines read alike)
-            const int row_off = ((uu + 3) & kMask) * kSlot + kRowSlot, op_off = ((uu + 1) & kMask) * kSlot;
+            const int row_off = ((uu + 3) & kMask) * kSlot, op_off = ((uu + 1) & kMask) * kSlot;  // (constants: uu is unrolled)
 #pragma unroll
             for (int t = 0; t < kNSL; ++t) {
 #pragma unroll
