@@ -20,6 +20,8 @@
 // consecutive rows" matters; the C layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) is the
 // dtype-independent 32x32 map.  A workgroup = 4 waves = 4 sample blocks (128 samples) x one row range, accumulators
 // in registers over the whole range (NWT * NFT tiles of 16 VGPRs per wave, one wave per SIMD).
+#include <cstdlib>
+
 #include "dmf_device.h"
 #include "dmf_internal.h"
 #include "dmf_fixedpoint.h"
@@ -385,7 +387,7 @@ __device__ __forceinline__ unsigned long long dmfg_stamp() {
 //   * digits: wave w converts rows 4 w .. 4 w + 3 of all 64 features (lane = feature), one dword per digit;
 //   * three A tiles: iteration b multiplies block b from operands read at the end of iteration b - 1, converts block
 //     b + 2 and reads the operands of block b + 1.
-template <int XL, int ND>
+template <int XL, int ND, int RING>
 __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restrict__ Dt8, int64_t plane_stride, int SB,
                                                     const double* __restrict__ Rtp, int nct, const double* __restrict__ u,
                                                     int64_t N, int n_c, int n_u, const short* __restrict__ feat_a,
@@ -402,8 +404,8 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
     constexpr int kSlotB = 4 * ND * 1024, kSlotX = XL * 4096, kSlot = kSlotB + kSlotX;  // B: [sample group][plane][1 KB]
     constexpr int kAtile = 2 * MA * 4;  // dwords of one block's A tile [2 (h)][MA][4]
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    char* __restrict__ ring = lds_raw;                                                            // [kRing][kSlot]
-    unsigned int* __restrict__ atile = reinterpret_cast<unsigned int*>(lds_raw + kRing * kSlot);  // [3][2 (h)][MA][4]
+    char* __restrict__ ring = lds_raw;                                                            // [RING][kSlot]
+    unsigned int* __restrict__ atile = reinterpret_cast<unsigned int*>(lds_raw + RING * kSlot);  // [3][2 (h)][MA][4]
     if (done_flag != nullptr && *done_flag) return;
 
     const int tid = threadIdx.x;
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
     const bool tail_clamp = r_end == N && (N & 31) != 0;  // only the last block of the last row range can run past N
     auto issue = [&](int j) {
         const int jc = j < nb ? j : nb - 1;  // beyond the range: a repeat of the last block keeps the DMA count uniform
-        char* __restrict__ slot = ring + (j % kRing) * kSlot;
+        char* __restrict__ slot = ring + (j % RING) * kSlot;
 #pragma unroll
         for (int x = 0; x < NDMA; ++x) {
             if (x >= n_dma) break;
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
     // rows of block j's two factors (this lane's feature, its four rows) into registers
     double xa[4], xv[4];
     auto read_rows = [&](int j) {
-        const char* __restrict__ xb = ring + (j % kRing) * kSlot + kSlotB;
+        const char* __restrict__ xb = ring + (j % RING) * kSlot + kSlotB;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             xa[r] = *reinterpret_cast<const double*>(xb + offA + r * strideA);  // (offset 0 without a feature)
@@ -540,15 +542,15 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
     auto load_operands = [&](int j, int abuf) {
 #pragma unroll
         for (int d = 0; d < ND; ++d)
-            bq[d] = *reinterpret_cast<const v4i*>(ring + (j % kRing) * kSlot + (sg * ND + d) * 1024 + lane * 16);
+            bq[d] = *reinterpret_cast<const v4i*>(ring + (j % RING) * kSlot + (sg * ND + d) * 1024 + lane * 16);
         const unsigned int* __restrict__ at = atile + abuf * kAtile + (((lane >> 5) * MA + 32 * fh + (lane & 31)) << 2);
 #pragma unroll
         for (int t = 0; t < kNSL; ++t) aop[t] = *reinterpret_cast<const v4i*>(at + ((t * MF) << 2));
     };
 
-    // prologue: kRing - 1 blocks in flight; digits of blocks 0 and 1; operands of block 0; rows of block 2
+    // prologue: RING - 1 blocks in flight; digits of blocks 0 and 1; operands of block 0; rows of block 2
 #pragma unroll 1
-    for (int j = 0; j < kRing - 1; ++j) issue(j);
+    for (int j = 0; j < RING - 1; ++j) issue(j);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_rows(0);
@@ -571,20 +573,19 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
     const char* __restrict__ rowB = ring + kSlotB + offB;
     const char* __restrict__ bsrc = ring + sg * ND * 1024 + lane * 16;
 #pragma unroll 1
-    for (int b0 = 0; b0 < nb; b0 += kRing) {
+    for (int b0 = 0; b0 < nb; b0 += RING) {
 #pragma unroll
-        for (int uu = 0; uu < kRing; ++uu) {
+        for (int uu = 0; uu < RING; ++uu) {
             const int b = b0 + uu;
             if (b >= nb) break;
-            constexpr int kMask = kRing - 1;
             const int a_next = a_cur == 2 ? 0 : a_cur + 1, a_gen = a_next == 2 ? 0 : a_next + 1;
             DMFG_STAMP(0)
             // own DMA of blocks <= b + 3 landed, own LDS traffic (digit writes, operand and row reads) done; then
             // everyone's (waves 0..3 have ND DMAs per block in flight, waves 4..7 XL)
-            // (the DMA of block b + kRing - 1 is issued further down, in the matrix phase: blocks b + 4 .. b + kRing - 2
+            // (the DMA of block b + RING - 1 is issued further down, in the matrix phase: blocks b + 4 .. b + RING - 2
             // may still be in flight here)
-            if (XL == ND || wave < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kRing - 5) * ND) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kRing - 5) * XL) : "memory");
+            if (XL == ND || wave < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 5) * ND) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 5) * XL) : "memory");
             DMFG_STAMP(1)
             __builtin_amdgcn_s_barrier();
             DMFG_STAMP(2)
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
             // matrix phase and only the seven digit stores remain behind it.  No branches: a wave beyond the last
             // sample block multiplies a repeat tile into accumulators that are never stored.
             const unsigned int* __restrict__ at_next = atile + a_next * kAtile + (((lane >> 5) * MA + 32 * fh + (lane & 31)) << 2);
-            const int row_off = ((uu + 3) & kMask) * kSlot, op_off = ((uu + 1) & kMask) * kSlot;  // (constants: uu is unrolled)
+            const int row_off = ((uu + 3) % RING) * kSlot, op_off = ((uu + 1) % RING) * kSlot;  // (constants: uu is unrolled)
 #pragma unroll
             for (int t = 0; t < kNSL; ++t) {
 #pragma unroll
@@ -618,11 +619,11 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
 #pragma unroll
             for (int d = 0; d < ND; ++d) bq[d] = *reinterpret_cast<const v4i*>(bsrc + d * 1024 + op_off);
             DMFG_STAMP(3)
-            {   // DMA of block b + kRing - 1 into the slot of block b - 1 (its count tile and rows went to registers long
+            {   // DMA of block b + RING - 1 into the slot of block b - 1 (its count tile and rows went to registers long
                 // ago), here rather than at the head of the iteration: while this wave waits for the load path to take
                 // the request, the other wave of the SIMD has matrix work to issue
-                const int j = b + kRing - 1, jc = j < nb ? j : nb - 1;  // beyond the range: a repeat keeps the DMA count uniform
-                char* __restrict__ slot = ring + ((uu + kRing - 1) & kMask) * kSlot;
+                const int j = b + RING - 1, jc = j < nb ? j : nb - 1;  // beyond the range: a repeat keeps the DMA count uniform
+                char* __restrict__ slot = ring + ((uu + RING - 1) % RING) * kSlot;
 #pragma unroll
                 for (int x = 0; x < NDMA; ++x) {
                     if (x >= n_dma) break;
@@ -903,25 +904,25 @@ size_t gram_i8_lds_bytes(int nft, int nd, int xl) {
     return (size_t)kRing * (4 * nd * 1024 + xl * 4096) + (size_t)2 * 2 * (kNSL * 32 * nft) * 16;
 }
 
-size_t gram_i8_w8_lds_bytes(int xl, int nd) { return (size_t)kRing * (4096 * nd + xl * 4096) + (size_t)3 * 2 * (kNSL * 64) * 16; }
+size_t gram_i8_w8_lds_bytes(int xl, int nd, int ring) { return (size_t)ring * (4096 * nd + xl * 4096) + (size_t)3 * 2 * (kNSL * 64) * 16; }
 
-template <int XL, int ND>
+template <int XL, int ND, int RING = kRing>
 static hipError_t launch_gram_i8_w8_t(const signed char* Dt8, int64_t plane_stride, int SD, const double* Rtp, const double* u,
                                       int64_t N, int n_c, int n_u, const short* fa, const short* fb, int NF, int p0, int MFtot,
                                       long long* slab, const int* done_flag, hipStream_t st) {
     int nsh, ny;
     int64_t rpw;
     gram_i8_geometry(N, SD, &nsh, &ny, &rpw);
-    const size_t lds = gram_i8_w8_lds_bytes(XL, ND);
+    const size_t lds = gram_i8_w8_lds_bytes(XL, ND, RING);
     static bool lds_limit_raised[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!lds_limit_raised[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gram_i8_w8<XL, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_gram_i8_w8<XL, ND, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_limit_raised[dev] = true;
     }
-    hipLaunchKernelGGL((k_gram_i8_w8<XL, ND>), dim3(nsh * ny), dim3(512), lds, st, Dt8, plane_stride, SD / 32, Rtp,
+    hipLaunchKernelGGL((k_gram_i8_w8<XL, ND, RING>), dim3(nsh * ny), dim3(512), lds, st, Dt8, plane_stride, SD / 32, Rtp,
                        (n_c + 3) / 4 * 4, u, N, n_c, n_u, fa, fb, NF, p0, MFtot, rpw, slab, SD, done_flag
 #ifdef DMF_STAMPS
                        , (unsigned long long*)nullptr
@@ -967,19 +968,26 @@ hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, 
     // the eight-wave kernel takes 64 features per launch (one count digit; two digits while the block's rows fit one
     // DMA piece: the LDS does not hold a ring of 16-KB slots), the four-wave kernel 64 / 32
     const bool wide = (n_c + 3) / 4 * 4 + n_u > 16;  // x image of a block beyond 4 KB: two DMA pieces per thread
-    const bool w8_nd2 = ND == 2 && !wide;
-    const int chunk = (ND == 1 || w8_nd2) ? 64 : 32;
+    const int chunk = 64;  // the eight-wave kernel; the four-wave kernel takes what is left when that is <= 32 (16) features
+    static const int w8_min = [] { const char* v = getenv("DMF_W8_MIN_NF"); return v != nullptr ? atoi(v) : -1; }();  // (experiments)
+    // (measured: the eight-wave form wins at every feature count -- config 2's 15 features 31 -> 28 us, 0+4 at 5e5 x 128
+    // 69 -> 53 us, a 10-feature second launch 145 -> ~100 us; DMF_W8_MIN_NF=33 brings the four-wave form back for small launches)
+    const int min1 = w8_min >= 0 ? w8_min : 0, min2 = w8_min >= 0 ? w8_min : 0;
     for (int p0 = 0; p0 < NF; p0 += chunk) {
         const int nf = NF - p0 < chunk ? NF - p0 : chunk;
         hipError_t e;
 #define DMF_GI8(F, D_, X)                                                                                                 \
     e = launch_gram_i8_t<F, D_, X>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st)
-        if (ND == 1 && nf > 32) {  // the headline shapes: eight waves, two per SIMD
+        if (ND == 1 && nf > min1) {  // the headline shapes: eight waves, two per SIMD
             if (wide) e = launch_gram_i8_w8_t<2, 1>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
             else e = launch_gram_i8_w8_t<1, 1>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
         }
-        else if (w8_nd2 && nf > 16)  // two count digits (some count above 127: what sequencing data looks like)
-            e = launch_gram_i8_w8_t<1, 2>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
+        else if (ND == 2 && nf > min2) {  // two count digits (some count above 127: what sequencing data looks like)
+            if (wide)  // (16-KB block slots: a ring of six is what the LDS holds beside the three A tiles)
+                e = launch_gram_i8_w8_t<2, 2, 6>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
+            else
+                e = launch_gram_i8_w8_t<1, 2>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
+        }
         else if (ND == 1) { if (wide) DMF_GI8(1, 1, 2); else DMF_GI8(1, 1, 1); }
         else { if (wide) DMF_GI8(1, 2, 2); else DMF_GI8(1, 2, 1); }
 #undef DMF_GI8

@@ -85,7 +85,7 @@ V2_CASES = [
     (1000, 64, 3, 2, 4, 3000, "counts up to ~3300: two balanced 8-bit digits (nd=2)"),
     (777, 30, 0, 1, 4, 40, "one feature only (u u), no known types"),
     (2000, 256, 16, 4, 3, 60, "74 features: two launches of the integer Gram (64 + 10)"),
-    (1500, 64, 16, 4, 3, 2500, "nd=2 with 74 features: three launches of 32"),
+    (1500, 64, 16, 4, 3, 2500, "nd=2 with 74 features and a wide row image: 64 on eight waves (ring of six) + 10 on four"),
     (4096, 256, 12, 4, 3, 60, "eight-wave Gram, 128 row ranges x 2 sample halves: the XCD-aware workgroup order"),
     (8197, 64, 12, 4, 3, 60, "eight-wave Gram, one sample quarter-group per range (nsh = 1), last block 5 rows"),
     (1013, 200, 10, 3, 3, 60, "eight-wave Gram, 36 features (28 lanes idle), ragged samples, natural workgroup order"),
