@@ -1153,15 +1153,6 @@ int dmf_solver_destroy(dmf_solver* s) {
     return DMF_OK;
 }
 
-// does the first launch of the integer Gram take the eight-wave kernel?  (mirrors launch_gram_i8)
-static bool gram_w8(int ND, int n_c, int n_u) {
-    const int nf = n_c * n_u + n_u * (n_u + 1) / 2;
-    const bool wide = (n_c + 3) / 4 * 4 + n_u > 16;
-    (void)wide;
-    (void)nf;
-    return ND == 1 || ND == 2;
-}
-
 int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t cap) {
     if (s == nullptr || buf == nullptr || cap < 1) return DMF_ERR_BAD_ARG;
     const dmf_problem* p = s->p;
@@ -1171,7 +1162,7 @@ int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t
         snprintf(row, sizeof(row), "k_rowpass_v2<%d,%d> nw=%d grid=%d tail=%d", (n_c + 3) / 4, n_u, (S + 63) / 64,
                  dmf::rowpass_v2_grid(p->N, S), (int)(p->N & 15));
         // (one count digit and more than 32 features: the eight-wave form of the integer Gram kernel takes the first 64)
-        snprintf(gram, sizeof(gram), "k_gram_i8<nd=%d>%s", p->ND, gram_w8(p->ND, n_c, n_u) ? "/w8" : "");
+        snprintf(gram, sizeof(gram), "k_gram_i8<nd=%d>/w8", p->ND);
     } else if (s->use_fused && n_iter2 <= kSplitInnerSteps) {
         const int64_t n_full = p->N - (p->N & 15);
         snprintf(row, sizeof(row), "k_rowpass_fused<%d,%d> nw=%d grid=%d tail=%d", (n_c + 3) / 4, n_u, (S + 63) / 64,
@@ -1185,7 +1176,7 @@ int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t
         else if (s->u_path == 1) snprintf(row, sizeof(row), "k_u_phase_gram");
         else snprintf(row, sizeof(row), "k_u_step_direct");
         if (s->use_gram_i8)
-            snprintf(gram, sizeof(gram), "k_bu_cols+k_gram_i8<nd=%d>%s", p->ND, gram_w8(p->ND, n_c, n_u) ? "/w8" : "");
+            snprintf(gram, sizeof(gram), "k_bu_cols+k_gram_i8<nd=%d>/w8", p->ND);
         else snprintf(gram, sizeof(gram), "%s", s->use_gram_spec ? "k_gram_u" : s->use_gram_mfma ? "k_gram_mfma" : "k_gram");
     }
     const bool tps = s->ctx->generic_level == 1 || s->ctx->generic_level == 2;

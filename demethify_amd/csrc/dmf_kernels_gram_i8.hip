@@ -7,7 +7,8 @@
 // exact small integer and Z lies in [0, 1], so the GEMM is evaluated WITHOUT rounding: Z is written in fixed point,
 // z ~ rint(z 2^52) = sum_t a_t 256^t with seven balanced 8-bit digits a_t in [-128, 127], the counts likewise as
 // one (d <= 127) or two (d <= 32639) balanced digits, every digit product is accumulated exactly in i32 by
-// v_mfma_i32_32x32x32_i8 and the per-workgroup sums are combined in 64-bit integer arithmetic (k_gram_v2_reduce): one conversion to f64 at the very end.  The only rounding against exact arithmetic is rint(z 2^52) of the exact product
+// v_mfma_i32_32x32x32_i8 and the per-workgroup sums are combined in 64-bit integer arithmetic (k_gram_v2_reduce): one
+// conversion to f64 at the very end.  The only rounding against exact arithmetic is rint(z 2^52) of the exact product
 // z = Rt_ik u_ij: |error| <= 2^-53 per feature value, an ulp of 1.0 -- far below a single rounding of an f64
 // accumulation of the same sum (2^-53 RELATIVE to a running sum of ~N d z / 2).  (FP64 needs one FMA per
 // (row, feature, sample); here the same product costs 7 i8 MACs at 64x the FP64 rate.)
@@ -15,11 +16,11 @@
 // Layouts.  B operand = counts as 8-bit digit planes Dt8[plane][row block of 32][sample block of 32][n 32][k 32]
 // (built once per problem, k_build_dt8): lane (n = l & 31, h = l >> 5) loads its 16 bytes k = 16 h .. 16 h + 15 with
 // one 16-B request, the wave 1 KB contiguous.  A operand = digit t of feature p for the block's 32 rows, generated
-// by the workgroup into LDS as Atile[h][m][16 B] (m = t * 32 NFT + p): conflict-free ds_read_b128 per (m, h).
+// by the workgroup into LDS as Atile[h][m][16 B] (m = 64 t + p): conflict-free ds_read_b128 per (m, h).
 // Any bijection (h, byte) -> k the hardware applies is the same for A and B, so only "16 bytes per lane = 16
 // consecutive rows" matters; the C layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) is the
-// dtype-independent 32x32 map.  A workgroup = 4 waves = 4 sample blocks (128 samples) x one row range, accumulators
-// in registers over the whole range (NWT * NFT tiles of 16 VGPRs per wave, one wave per SIMD).
+// dtype-independent 32x32 map.  A workgroup = 8 waves = 4 sample blocks (128 samples) x 2 feature halves x one row
+// range, accumulators in registers over the whole range (7 or 8 tiles of 16 VGPRs per wave, two waves per SIMD).
 #include <cstdlib>
 
 #include "dmf_device.h"
@@ -163,201 +164,10 @@ hipError_t launch_gather_counts_int(const unsigned short* src16, const long long
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------ the GEMM
+// ------------------------------------------------------------------------------------------------ the GEMM (eight waves)
 typedef __attribute__((address_space(1))) const void gmem_void;
 typedef __attribute__((address_space(3))) int lds_int;
 
-// Per 32-row block the workgroup needs 1 KB of count digits per wave and plane (B operand) and the block's rows of
-// R_trunc and u (32 K doubles).  Both arrive by LDS-DMA (global_load_lds_dwordx4: no VGPR destination, requests stay
-// in flight across barriers) into a ring of kRing block slots, kRing - 1 blocks ahead of their use: a block takes
-// ~0.3 us, an HBM miss under load several times that, and with ~500 accumulator / operand registers per wave there is
-// one wave per SIMD and no register room to stage that many loads.  Every wave issues the same number of DMA
-// instructions per block (ND + XL), so "block b + 1 has landed" is the counted wait vmcnt((kRing - 2)(ND + XL)) followed
-// by the workgroup barrier (the compiler does not order LDS reads behind LDS-DMA: the wait + barrier pair does).
-template <int NFT, int ND, int XL>
-__global__ __launch_bounds__(256) void k_gram_i8(const signed char* __restrict__ Dt8, int64_t plane_stride, int SB,
-                                                 const double* __restrict__ Rtp, int nct, const double* __restrict__ u,
-                                                 int64_t N, int n_c, int n_u, const short* __restrict__ feat_a,
-                                                 const short* __restrict__ feat_b, int NF, int p0, int MFtot,
-                                                 int64_t rows_per_wg, long long* __restrict__ slab, int SDs,
-                                                 const int* __restrict__ done_flag) {
-    // features [p0, p0 + NF) of the table, NF <= 32 NFT: one launch per chunk of features (accumulator registers);
-    // MFtot = feature slots of the whole slab
-    constexpr int NWT = kNSL + ND - 1;   // digit weights 256^0 .. 256^(NWT-1)
-    constexpr int MF = 32 * NFT;         // feature slots per digit (<= 64: lane = feature)
-    constexpr int MA = kNSL * MF;        // rows of the A tile
-    constexpr int kSlotB = 4 * ND * 1024, kSlotX = XL * 4096, kSlot = kSlotB + kSlotX;
-    constexpr int kDmaPerBlock = ND + XL;
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    char* __restrict__ ring = lds_raw;                                                            // [kRing][kSlot]
-    unsigned int* __restrict__ atile = reinterpret_cast<unsigned int*>(lds_raw + kRing * kSlot);  // [2][2 (h)][MA][4]
-    if (done_flag != nullptr && *done_flag) return;
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int sb = blockIdx.x * 4 + wave;  // this wave's block of 32 samples
-    const bool wave_on = sb < SB;
-    const int sbc = wave_on ? sb : SB - 1;
-    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_wg;  // multiple of 32
-    int64_t r_end = r_begin + rows_per_wg;
-    if (r_end > N) r_end = N;
-    const int nb = r_end > r_begin ? (int)((r_end - r_begin + 31) / 32) : 0;
-    if (nb == 0) return;
-
-    for (int i = tid; i < 2 * 2 * MA * 4; i += 256) atile[i] = 0u;  // feature slots >= NF stay zero digits
-
-    // this lane's feature (lane = p): byte offsets of its two factors inside a block's x image
-    // [R_trunc rows: 32 x nct doubles (the padded copy: rows of 4 ceil(n_c / 4))][u rows: 32 x n_u doubles]
-    const bool feat_on = lane < NF;
-    int offA = 0, strideA = 0, offB = 0, strideB = 0;
-    if (feat_on) {
-        const int ia = feat_a[p0 + lane], ib = feat_b[p0 + lane];
-        offA = ia < n_c ? ia * 8 : 256 * nct + (ia - n_c) * 8;
-        strideA = ia < n_c ? nct * 8 : n_u * 8;
-        offB = ib < n_c ? ib * 8 : 256 * nct + (ib - n_c) * 8;
-        strideB = ib < n_c ? nct * 8 : n_u * 8;
-    }
-
-    v16i acc[NWT * NFT];
-#pragma unroll
-    for (int a = 0; a < NWT * NFT; ++a)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][e] = 0;
-
-    const int n_chunk_rt = 16 * nct, n_chunks = 16 * (nct + n_u);  // 16-B pieces of a block's x image
-    // last 16-B piece of each array: rows of the padded R_trunc copy are multiples of 32 B; u may end on an odd
-    // double, its allocation is rounded up to 16 B by the solver (dmf_api.hip)
-    const int64_t rt_last = nct > 0 ? N * nct * 8 - 16 : 0;
-    const int64_t u_last = (N * n_u * 8 - 8) & ~(int64_t)15;
-    const int b_lane_off = (lane & 31) * 32 + (lane >> 5) * 16;  // Dt8 tile [n][k]: this lane's 16 bytes (n = l & 31, h = l >> 5)
-    const int64_t rb0 = r_begin >> 5;
-
-    auto issue = [&](int j) {
-        const int jc = j < nb ? j : nb - 1;  // beyond the range: a repeat of the last block keeps the DMA count uniform
-        char* __restrict__ slot = ring + (j % kRing) * kSlot;
-        const signed char* __restrict__ src = Dt8 + ((rb0 + jc) * SB + sbc) * 1024 + b_lane_off;
-#pragma unroll
-        for (int d = 0; d < ND; ++d)
-            __builtin_amdgcn_global_load_lds((gmem_void*)(src + d * plane_stride), (lds_int*)(slot + (wave * ND + d) * 1024), 16, 0, 0);
-        const int64_t row0 = r_begin + (int64_t)jc * 32;
-#pragma unroll
-        for (int x = 0; x < XL; ++x) {
-            int c = tid + 256 * x;
-            if (c >= n_chunks) c = n_chunks - 1;  // lands in the slot's padding
-            const char* g;
-            if (c < n_chunk_rt) {
-                int64_t off = row0 * nct * 8 + (int64_t)c * 16;
-                g = reinterpret_cast<const char*>(Rtp) + (off < rt_last ? off : rt_last);
-            } else {
-                int64_t off = row0 * n_u * 8 + (int64_t)(c - n_chunk_rt) * 16;
-                g = reinterpret_cast<const char*>(u) + (off < u_last ? off : u_last);
-            }
-            __builtin_amdgcn_global_load_lds((gmem_void*)g, (lds_int*)(slot + kSlotB + (x * 4 + wave) * 1024), 16, 0, 0);
-        }
-    };
-    // digits of block j's features into A tile `buf`: wave w = rows 8 w .. 8 w + 7, lane = feature
-    auto generate = [&](int buf, int j) {
-        const char* __restrict__ xb = ring + (j % kRing) * kSlot + kSlotB;
-        unsigned int lo[8], hi[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int row = 8 * wave + r;
-            const double xa0 = *reinterpret_cast<const double*>(xb + offA + row * strideA);  // (offset 0 without a feature)
-            const double xa = feat_on ? xa0 : 0.0;
-            const double xv = *reinterpret_cast<const double*>(xb + offB + row * strideB);
-            z_to_biased(xa, xv, lo[r], hi[r]);
-        }
-        unsigned int dg[2][8];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const unsigned int l4[4] = {lo[4 * half], lo[4 * half + 1], lo[4 * half + 2], lo[4 * half + 3]};
-            const unsigned int h4[4] = {hi[4 * half], hi[4 * half + 1], hi[4 * half + 2], hi[4 * half + 3]};
-            unsigned int tl[4], th[4];
-            transpose4(l4, tl);
-            transpose4(h4, th);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) dg[half][t] = tl[t] ^ 0x80808080u;
-            dg[half][4] = th[0] ^ 0x80808080u;
-            dg[half][5] = th[1] ^ 0x80808080u;
-            dg[half][6] = th[2];
-        }
-        unsigned int* __restrict__ at = atile + buf * (2 * MA * 4) + (((wave >> 1) * MA + lane) << 2) + (wave & 1) * 2;
-        if (MF == 64 || lane < MF) {  // (lane = feature slot; with 32 slots the upper half-wave has none)
-#pragma unroll
-            for (int t = 0; t < kNSL; ++t) {
-                typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<v2u*>(at + ((t * MF) << 2)) = v2u{dg[0][t], dg[1][t]};
-            }
-        }
-    };
-
-    // ---- prologue: kRing - 1 blocks in flight, block 0's digits generated
-#pragma unroll 1
-    for (int j = 0; j < kRing - 1; ++j) issue(j);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    generate(0, 0);
-
-#pragma unroll 1
-    for (int b = 0; b < nb; ++b) {
-        const int cur = b & 1;
-        issue(b + kRing - 1);  // into the slot of block b - 1, consumed before the previous barrier
-        // own DMA of blocks <= b + 1 landed, own LDS writes (A[cur]) done; then everyone's
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((kRing - 2) * kDmaPerBlock) : "memory");
-        __builtin_amdgcn_s_barrier();
-        // (no branches in here: a wave beyond the last sample block multiplies a repeat tile into accumulators that
-        // are never stored, lanes without a feature produce the all-zero digits of z = 0 -- so that the scheduler may
-        // place the digit arithmetic of block b + 1 under the matrix-core time of block b)
-        const char* __restrict__ bs = ring + (b % kRing) * kSlot + wave * ND * 1024 + lane * 16;
-        v4i bq[ND];
-#pragma unroll
-        for (int d = 0; d < ND; ++d) bq[d] = *reinterpret_cast<const v4i*>(bs + d * 1024);
-        const unsigned int* __restrict__ at = atile + cur * (2 * MA * 4) + (((lane >> 5) * MA + (lane & 31)) << 2);
-        v4i aop[kNSL * NFT];  // every A operand of the block up front: one LDS round trip, not one per MFMA
-#pragma unroll
-        for (int t = 0; t < kNSL; ++t)
-#pragma unroll
-            for (int f = 0; f < NFT; ++f) aop[t * NFT + f] = *reinterpret_cast<const v4i*>(at + ((t * MF + 32 * f) << 2));
-        generate(cur ^ 1, b + 1 < nb ? b + 1 : b);
-#pragma unroll
-        for (int t = 0; t < kNSL; ++t)
-#pragma unroll
-            for (int f = 0; f < NFT; ++f)
-#pragma unroll
-                for (int d = 0; d < ND; ++d)
-                    acc[(t + d) * NFT + f] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[t * NFT + f], bq[d], acc[(t + d) * NFT + f], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (repeat) DMAs must not outlive the workgroup's LDS
-
-    // ---- slab[y][half][feature slot][sample] (i64): the exact partial sums of this row range with the digit weights
-    // applied inside each half, lo = sum_{w < 4} acc_w 256^w, hi = sum_{w >= 4} acc_w 256^(w - 4)  (|acc_w| < 2^31, so
-    // both fit 56 bits); the full sum is lo + 2^32 hi
-    if (wave_on) {
-        const int n = lane & 31, h = lane >> 5;
-        long long* __restrict__ out = slab + ((int64_t)blockIdx.y * 2 * MFtot + p0) * SDs + sb * 32 + n;
-#pragma unroll
-        for (int f = 0; f < NFT; ++f)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int p = 32 * f + m;
-                long long lo = 0, hi = 0;
-#pragma unroll
-                for (int wt = 0; wt < NWT; ++wt) {
-                    const long long v = (long long)acc[wt * NFT + f][e];
-                    if (wt < 4) lo += v << (8 * wt);
-                    else hi += v << (8 * (wt - 4));
-                }
-                if (p < NF) {
-                    out[(int64_t)p * SDs] = lo;
-                    out[(int64_t)(MFtot + p) * SDs] = hi;
-                }
-            }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ the GEMM, 8 waves
 // Diagnostic build only (tools/gram_i8_probe.hip defines DMF_STAMPS): per-wave cycle sums of the block loop's segments.
 #ifdef DMF_STAMPS
 #define DMFG_STAMP_DECL unsigned long long st_last = dmfg_stamp(), st_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -376,17 +186,22 @@ __device__ __forceinline__ unsigned long long dmfg_stamp() {
 #define DMFG_STAMP_FLUSH
 #endif
 
-// The headline shapes (one count digit, 33..64 features): the same product on EIGHT waves, two per SIMD.  In-kernel
-// stamps of the four-wave kernel above showed its 2.0 k cycles per 32-row block to be one wave's serial instruction
-// stream -- DMA issue 0.35 k, LDS round trips 0.5 k + 0.4 k, digit arithmetic 0.6 k, 14 MFMAs 0.45 k of matrix pipe --
-// and reordering that stream (operands preloaded a block ahead, MFMAs interleaved with the digit arithmetic) moved
-// nothing: with 480 registers there is one wave per SIMD and nobody to issue while it waits.  Here a wave keeps ONE
-// feature half (32 features x 32 samples x 7 digits = 112 accumulator registers), wave = (sample group w & 3, feature
-// half w >> 2), so that two waves share a SIMD and each other's LDS / DMA / barrier waits:
-//   * DMA per block: waves 0..3 fetch the count tile of their sample group, waves 4..7 the XL pieces of the x image;
-//   * digits: wave w converts rows 4 w .. 4 w + 3 of all 64 features (lane = feature), one dword per digit;
-//   * three A tiles: iteration b multiplies block b from operands read at the end of iteration b - 1, converts block
-//     b + 2 and reads the operands of block b + 1.
+// Per 32-row block the workgroup needs 1 KB of count digits per sample group and plane (B operand) and the block's rows
+// of R_trunc and u.  Both arrive by LDS-DMA (global_load_lds_dwordx4: no VGPR destination, requests stay in flight across
+// barriers) into a ring of RING block slots; "landed" is a counted s_waitcnt vmcnt(n) followed by the block's one barrier
+// (the compiler does not order LDS reads behind LDS-DMA: the wait + barrier pair does).
+//
+// Eight waves, two per SIMD.  The first version of this kernel had four waves with all 64 features' accumulators each
+// (~480 registers, one wave per SIMD); in-kernel stamps showed its 2.0 k cycles per 32-row block to be one wave's
+// serial instruction stream -- DMA issue 0.35 k, LDS round trips 0.5 k + 0.4 k, digit arithmetic 0.6 k, 14 MFMAs 0.45 k of
+// matrix pipe -- and reordering that stream moved nothing: nobody to issue while the wave waits.  Here a wave keeps ONE
+// feature half (32 features x 32 samples x 7 or 8 digit weights = 112 / 128 accumulator registers), wave = (sample group
+// w & 3, feature half w >> 2), so that two waves share a SIMD and each other's LDS / DMA / barrier waits:
+//   * DMA per block: waves 0..3 fetch the ND count planes of their sample group, waves 4..7 the XL pieces of the x image;
+//   * digits: wave w converts 16 features x 16 rows (lane = feature l & 15, row quad l >> 4), one dword per digit;
+//   * three A tiles: iteration b multiplies block b from operands read during iteration b - 1, converts block b + 2 and
+//     reads the operands of block b + 1.
+// It is used at every feature count (it beat the four-wave form, since removed, also at 10..15 features).
 template <int XL, int ND, int RING>
 __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restrict__ Dt8, int64_t plane_stride, int SB,
                                                     const double* __restrict__ Rtp, int nct, const double* __restrict__ u,
@@ -900,10 +715,6 @@ int64_t gram_i8_acc_words(int S, int n_c, int n_u) {
     return (int64_t)2 * nf * S + (int64_t)kRedChunks * n_u * S + ((int64_t)(nf + n_u) * ((S + 63) / 64) + 1) / 2;
 }
 
-size_t gram_i8_lds_bytes(int nft, int nd, int xl) {
-    return (size_t)kRing * (4 * nd * 1024 + xl * 4096) + (size_t)2 * 2 * (kNSL * 32 * nft) * 16;
-}
-
 size_t gram_i8_w8_lds_bytes(int xl, int nd, int ring) { return (size_t)ring * (4096 * nd + xl * 4096) + (size_t)3 * 2 * (kNSL * 64) * 16; }
 
 template <int XL, int ND, int RING = kRing>
@@ -931,28 +742,6 @@ static hipError_t launch_gram_i8_w8_t(const signed char* Dt8, int64_t plane_stri
     return hipGetLastError();
 }
 
-template <int NFT, int ND, int XL>
-static hipError_t launch_gram_i8_t(const signed char* Dt8, int64_t plane_stride, int SD, const double* Rtp, const double* u,
-                                   int64_t N, int n_c, int n_u, const short* fa, const short* fb, int NF, int p0, int MFtot,
-                                   long long* slab, const int* done_flag, hipStream_t st) {
-    int nsh, ny;
-    int64_t rpw;
-    gram_i8_geometry(N, SD, &nsh, &ny, &rpw);
-    const size_t lds = gram_i8_lds_bytes(NFT, ND, XL);
-    static bool lds_limit_raised[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (lds > 48 * 1024 && !lds_limit_raised[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gram_i8<NFT, ND, XL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
-        if (e != hipSuccess) return e;
-        lds_limit_raised[dev] = true;
-    }
-    hipLaunchKernelGGL((k_gram_i8<NFT, ND, XL>), dim3(nsh, ny), dim3(256), lds, st, Dt8, plane_stride, SD / 32, Rtp,
-                       (n_c + 3) / 4 * 4, u, N, n_c, n_u, fa, fb, NF, p0, MFtot, rpw, slab, SD, done_flag);
-    return hipGetLastError();
-}
-
 hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, int ND, const double* Rtp, const double* u,
                           int64_t N, int n_c, int n_u, const short* fa, const short* fb, int NF, long long* slab,
                           int64_t slab_words, const int* done_flag, int* ny_out, hipStream_t st) {
@@ -963,34 +752,21 @@ hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, 
     const int MFtot = (NF + 31) / 32 * 32;
     // every workgroup (row range) writes its own [2][MFtot][SD] slab: the buffer must hold all of them
     if ((int64_t)ny * 2 * MFtot * SD > slab_words || rpw * 128 * 128 * ND >= (int64_t)1 << 31) return hipErrorInvalidValue;
-    // accumulator registers: (7 + ND - 1) * NFT tiles of 16 per wave -> 64 features per launch with one count digit,
-    // 32 with two; more features = more launches over the (small) 8-bit planes
-    // the eight-wave kernel takes 64 features per launch (one count digit; two digits while the block's rows fit one
-    // DMA piece: the LDS does not hold a ring of 16-KB slots), the four-wave kernel 64 / 32
+    // more than 64 features = more launches over the (small) 8-bit planes
+    const int chunk = 64;  // features per launch (lane = feature slot of a 64-lane wave; two feature halves of 32)
     const bool wide = (n_c + 3) / 4 * 4 + n_u > 16;  // x image of a block beyond 4 KB: two DMA pieces per thread
-    const int chunk = 64;  // the eight-wave kernel; the four-wave kernel takes what is left when that is <= 32 (16) features
-    static const int w8_min = [] { const char* v = getenv("DMF_W8_MIN_NF"); return v != nullptr ? atoi(v) : -1; }();  // (experiments)
-    // (measured: the eight-wave form wins at every feature count -- config 2's 15 features 31 -> 28 us, 0+4 at 5e5 x 128
-    // 69 -> 53 us, a 10-feature second launch 145 -> ~100 us; DMF_W8_MIN_NF=33 brings the four-wave form back for small launches)
-    const int min1 = w8_min >= 0 ? w8_min : 0, min2 = w8_min >= 0 ? w8_min : 0;
     for (int p0 = 0; p0 < NF; p0 += chunk) {
         const int nf = NF - p0 < chunk ? NF - p0 : chunk;
         hipError_t e;
-#define DMF_GI8(F, D_, X)                                                                                                 \
-    e = launch_gram_i8_t<F, D_, X>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st)
-        if (ND == 1 && nf > min1) {  // the headline shapes: eight waves, two per SIMD
+        if (ND == 1) {
             if (wide) e = launch_gram_i8_w8_t<2, 1>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
             else e = launch_gram_i8_w8_t<1, 1>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
-        }
-        else if (ND == 2 && nf > min2) {  // two count digits (some count above 127: what sequencing data looks like)
+        } else {  // two count digits (some count above 127: what sequencing data looks like)
             if (wide)  // (16-KB block slots: a ring of six is what the LDS holds beside the three A tiles)
                 e = launch_gram_i8_w8_t<2, 2, 6>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
             else
                 e = launch_gram_i8_w8_t<1, 2>(Dt8, plane_stride, SD, Rtp, u, N, n_c, n_u, fa, fb, nf, p0, MFtot, slab, done_flag, st);
         }
-        else if (ND == 1) { if (wide) DMF_GI8(1, 1, 2); else DMF_GI8(1, 1, 1); }
-        else { if (wide) DMF_GI8(1, 2, 2); else DMF_GI8(1, 2, 1); }
-#undef DMF_GI8
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
