@@ -933,10 +933,16 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     // Measured at 5e5 x 128 (tools/gram_i8_vs_fp64.py): 6+6 (57 features) 0.25 against 0.35 ms for k_gram_u, but 0+5 / 0+8 /
     // 0+12 0.25 / 0.25 / 0.34 against 0.19 / 0.22 / 0.31 ms -- without known types the FP64 Gram is cheap and the four
     // launches of this route are not; so: only with known types and at least 40 features.
+    // What the integer route competes with is k_gram_u, whose time grows with its accumulator count (padded known types
+    // x unknowns + pairs + b_u) while the integer route is flat (k_bu_cols dominates it): at 5e5 x 128 the FP64 kernel
+    // takes 0.21 ms with 51 accumulators (2+6, 4+6), 0.23 with 40 (1+5, 3+5), 0.36 with 60..76 (5+5, 1+8, 3+8), the
+    // integer route 0.23..0.24 throughout (tools/gram_i8_vs_fp64.py).  DMF_GRAM_I8_MIN moves the threshold (experiments).
+    static const int i8_min_features = [] { const char* v = getenv("DMF_GRAM_I8_MIN"); return v != nullptr ? atoi(v) : 56; }();
+    const int fp64_acc = (int)((n_c + 3) / 4 * 4 * n_u + n_u * (n_u + 1) / 2 + n_u);
     static const bool i8_nc0 = [] { const char* v = getenv("DMF_GRAM_I8_NC0"); return v != nullptr && v[0] == '1'; }();  // (experiments)
     const bool known_ok = n_c > 0 ? (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0) : i8_nc0;
     s->use_gram_i8 = ctx->generic_level == 0 && p->ND > 0 && p->D16 != nullptr && known_ok &&
-                     n_c * n_u + n_u * (n_u + 1) / 2 >= (n_c > 0 ? 40 : 33) && n_u <= 20 &&
+                     (n_c > 0 ? fp64_acc >= i8_min_features : n_c * n_u + n_u * (n_u + 1) / 2 >= 33) && n_u <= 20 &&
                      dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
     if (s->use_v2) {
         // the row pass writes alpha_j alpha_l in fixed point on [0, 1]: true of every iterate (columns on the simplex),

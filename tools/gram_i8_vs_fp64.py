@@ -12,7 +12,8 @@ from demethify_amd.device import Context, Problem, Solver
 dev = torch.device("cuda", 0)
 ctx = Context(0)
 N, S = 500_000, 128
-for n_c, n_u in [(0, 5), (0, 8), (0, 12), (6, 6)]:
+shapes = [tuple(int(x) for x in a.split('+')) for a in sys.argv[1:]] or [(0, 5), (0, 8), (0, 12), (6, 6)]
+for n_c, n_u in shapes:
     V, D, Rt = make_inputs_on_device(torch, dev, N, S, max(n_c, 1), n_u, seed=0)
     rs = np.random.RandomState(1)
     u0 = rs.uniform(size=(N, n_u)); a0 = rs.dirichlet(np.ones(n_c + n_u), S).T
