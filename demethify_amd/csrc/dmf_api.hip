@@ -936,8 +936,9 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     // What the integer route competes with is k_gram_u, whose time grows with its accumulator count (padded known types
     // x unknowns + pairs + b_u) while the integer route is flat (k_bu_cols dominates it): at 5e5 x 128 the FP64 kernel
     // takes 0.21 ms with 51 accumulators (2+6, 4+6), 0.23 with 40 (1+5, 3+5), 0.36 with 60..76 (5+5, 1+8, 3+8), the
-    // integer route 0.23..0.24 throughout (tools/gram_i8_vs_fp64.py).  DMF_GRAM_I8_MIN moves the threshold (experiments).
-    static const int i8_min_features = [] { const char* v = getenv("DMF_GRAM_I8_MIN"); return v != nullptr ? atoi(v) : 56; }();
+    // integer route 0.20..0.21 throughout with two samples per lane in k_bu_cols2 (tools/gram_i8_vs_fp64.py): from 48
+    // accumulators on.  DMF_GRAM_I8_MIN moves the threshold (experiments).
+    static const int i8_min_features = [] { const char* v = getenv("DMF_GRAM_I8_MIN"); return v != nullptr ? atoi(v) : 48; }();
     const int fp64_acc = (int)((n_c + 3) / 4 * 4 * n_u + n_u * (n_u + 1) / 2 + n_u);
     static const bool i8_nc0 = [] { const char* v = getenv("DMF_GRAM_I8_NC0"); return v != nullptr && v[0] == '1'; }();  // (experiments)
     const bool known_ok = n_c > 0 ? (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0) : i8_nc0;

@@ -21,6 +21,7 @@
 // consecutive rows" matters; the C layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) is the
 // dtype-independent 32x32 map.  A workgroup = 8 waves = 4 sample blocks (128 samples) x 2 feature halves x one row
 // range, accumulators in registers over the whole range (7 or 8 tiles of 16 VGPRs per wave, two waves per SIMD).
+#include <cstdint>
 #include <cstdlib>
 
 #include "dmf_device.h"
@@ -528,6 +529,66 @@ __global__ __launch_bounds__(256) void k_bu_cols(const double* __restrict__ V, c
     }
 }
 
+// The same stream with TWO adjacent samples per lane (S even, 16-byte aligned V): one 16-byte load of V and one 4-byte
+// load of the counts per row and lane -- half the load instructions per byte (the 2-byte-per-lane count load of the form
+// above is the worst shape for the load path).  Same per-element arithmetic; slab layout unchanged.
+template <int NU>
+__global__ __launch_bounds__(256) void k_bu_cols2(const double* __restrict__ V, const unsigned short* __restrict__ D16, int SD,
+                                                  const double* __restrict__ u, int64_t N, int S, double* __restrict__ slab,
+                                                  const int* __restrict__ done_flag) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    constexpr int kRows = 8;
+    __shared__ double red[3][NU][2][64];
+    if (done_flag != nullptr && *done_flag) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int s = blockIdx.y * 128 + 2 * lane;
+    const bool active = s < S;  // (S even: both samples or none)
+    const int sc = active ? s : S - 2;
+    double acc[NU][2];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) acc[j][0] = acc[j][1] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t i0 = (int64_t)blockIdx.x * 4 + wave; i0 < N; i0 += kRows * stride) {
+        double t0[kRows], t1[kRows];
+        int64_t row[kRows];
+#pragma unroll
+        for (int x = 0; x < kRows; ++x) {
+            const int64_t i = i0 + x * stride;
+            row[x] = i < N ? i : N - 1;
+            const unsigned int dd = i < N ? *reinterpret_cast<const unsigned int*>(D16 + row[x] * SD + sc) : 0u;
+            const v2d v = *reinterpret_cast<const v2d*>(V + row[x] * S + sc);
+            t0[x] = (double)(dd & 0xFFFFu) * v.x;
+            t1[x] = (double)(dd >> 16) * v.y;
+        }
+#pragma unroll
+        for (int x = 0; x < kRows; ++x) {
+            const double* __restrict__ u_row = u + row[x] * NU;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const double uj = u_row[j];
+                acc[j][0] = fma(t0[x], uj, acc[j][0]);
+                acc[j][1] = fma(t1[x], uj, acc[j][1]);
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            red[wave - 1][j][0][lane] = acc[j][0];
+            red[wave - 1][j][1][lane] = acc[j][1];
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && active) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            double* __restrict__ out = slab + ((int64_t)blockIdx.x * NU + j) * S + s;
+            out[0] = ((acc[j][0] + red[0][j][0][lane]) + red[1][j][0][lane]) + red[2][j][0][lane];
+            out[1] = ((acc[j][1] + red[0][j][1][lane]) + red[1][j][1][lane]) + red[2][j][1][lane];
+        }
+    }
+}
+
 int bu_cols_grid(int64_t N) {
     int64_t want = (N + 4 * 8 - 1) / (4 * 8);
     if (want > 512) want = 512;
@@ -538,7 +599,18 @@ hipError_t launch_bu_cols(const double* V, const unsigned short* D16, int SD, co
                           double* slab, const int* done_flag, int* n_slabs_out, hipStream_t st) {
     const int nbx = bu_cols_grid(N);
     *n_slabs_out = nbx;
-    const dim3 grid(nbx, (S + 63) / 64), block(256);
+    const dim3 block(256);
+    if ((S & 1) == 0 && (SD & 1) == 0 && S >= 128 && n_u <= 10 && (reinterpret_cast<uintptr_t>(V) & 15) == 0) {
+        const dim3 grid2(nbx, (S + 127) / 128);
+        switch (n_u) {  // (LDS for the cross-wave sum: 3 x NU x 2 x 64 doubles <= 30 KB up to ten unknowns)
+#define DMF_CASE2(NU_) \
+    case NU_: hipLaunchKernelGGL((k_bu_cols2<NU_>), grid2, block, 0, st, V, D16, SD, u, N, S, slab, done_flag); return hipGetLastError();
+            DMF_CASE2(1) DMF_CASE2(2) DMF_CASE2(3) DMF_CASE2(4) DMF_CASE2(5) DMF_CASE2(6) DMF_CASE2(7) DMF_CASE2(8) DMF_CASE2(9) DMF_CASE2(10)
+#undef DMF_CASE2
+            default: break;
+        }
+    }
+    const dim3 grid(nbx, (S + 63) / 64);
     switch (n_u) {
 #define DMF_CASE(NU_) \
     case NU_: hipLaunchKernelGGL((k_bu_cols<NU_>), grid, block, 0, st, V, D16, SD, u, N, S, slab, done_flag); break;
