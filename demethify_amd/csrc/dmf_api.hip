@@ -941,7 +941,9 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     static const int i8_min_features = [] { const char* v = getenv("DMF_GRAM_I8_MIN"); return v != nullptr ? atoi(v) : 48; }();
     const int fp64_acc = (int)((n_c + 3) / 4 * 4 * n_u + n_u * (n_u + 1) / 2 + n_u);
     static const bool i8_nc0 = [] { const char* v = getenv("DMF_GRAM_I8_NC0"); return v != nullptr && v[0] == '1'; }();  // (experiments)
-    const bool known_ok = n_c > 0 ? (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0) : i8_nc0;
+    // (without known types the integer route pays only at exactly 8 unknowns -- 36 features: 0.24 -> 0.20 ms; 9 and more
+    // are equal to k_gram_u: DMF_GRAM_I8_NC0=1 forces it for experiments)
+    const bool known_ok = n_c > 0 ? (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0) : (i8_nc0 || n_u <= 8);
     s->use_gram_i8 = ctx->generic_level == 0 && p->ND > 0 && p->D16 != nullptr && known_ok &&
                      (n_c > 0 ? fp64_acc >= i8_min_features : n_c * n_u + n_u * (n_u + 1) / 2 >= 33) && n_u <= 20 &&
                      dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
