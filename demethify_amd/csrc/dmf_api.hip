@@ -429,12 +429,12 @@ int enqueue_u_phase(dmf_solver* s, int n_iter2) {
             HIP_TRY(pool_alloc(ctx, (void**)&s->beta_tab, (size_t)n_iter2 * sizeof(double)));
             s->beta_cap = n_iter2;
         }
-        HIP_TRY(dmf::launch_u_phase_split(p->V, p->D, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, (int)p->S,
+        HIP_TRY(dmf::launch_u_phase_split(p->V, p->D, p->D16, p->SD, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, (int)p->S,
                                           (int)p->n_c, (int)s->n_u, n_iter2, s->mode, s->cm, s->beta_tab, ctx->stream));
         return DMF_OK;
     }
     if (s->u_path == 0) {
-        HIP_TRY(dmf::launch_u_phase_mfma(p->V, p->D, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N,
+        HIP_TRY(dmf::launch_u_phase_mfma(p->V, p->D, p->D16, p->SD, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N,
                                          (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
     } else if (s->u_path == 1) {
         HIP_TRY(dmf::launch_u_phase_gram(p->V, p->D, p->Rt, s->alpha, s->u, s->u_prev, s->state, p->N,
@@ -550,7 +550,7 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
         if (n_tail > 0) {
             const double* rt_tail = p->Rtp ? p->Rtp + n_full * nct : nullptr;
             double* u_tail = s->u + n_full * n_u;
-            HIP_TRY(dmf::launch_u_phase_mfma(p->V + n_full * S, p->D + n_full * S, rt_tail, s->alpha, u_tail,
+            HIP_TRY(dmf::launch_u_phase_mfma(p->V + n_full * S, p->D + n_full * S, nullptr, 0, rt_tail, s->alpha, u_tail,
                                              s->u_prev + n_full * n_u, s->state, n_tail, S, n_c, n_u, n_iter2,
                                              s->mode, ctx->stream));
             HIP_TRY(dmf::launch_sumsq_f64(u_tail, n_tail * n_u, ctx->scratch, s->u2_partials + grid, &s->state->done,

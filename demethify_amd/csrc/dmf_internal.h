@@ -107,8 +107,8 @@ hipError_t launch_u_phase_gram(const double* V, const double* D, const double* R
 bool u_phase_gram_supported(int S, int n_c, int n_u);
 // u phase on the FP64 matrix cores (n_u <= 8, n_c <= 16, S <= 512); takes the padded Rtp as well
 bool u_phase_mfma_supported(int S, int n_c, int n_u);
-hipError_t launch_u_phase_mfma(const double* V, const double* D, const double* Rtp, const double* alpha,
-                               double* u, double* u_prev, const SolverState* state, int64_t N, int S,
+hipError_t launch_u_phase_mfma(const double* V, const double* D, const unsigned short* D16, int SD, const double* Rtp,
+                               const double* alpha, double* u, double* u_prev, const SolverState* state, int64_t N, int S,
                                int n_c, int n_u, int n_iter2, int mode, hipStream_t st);
 // fused row pass: u phase + u-dependent Gram slab + ||u||^2 / l_h in one read of V and D
 // (S % 4 == 0, S <= 256, n_c <= 16, n_u <= 8, accumulators <= 80, counts exact in f32);
@@ -149,9 +149,9 @@ hipError_t launch_init_state(SolverState* state, const double* consts, const dou
 // the same u phase in two launches for many inner steps: c_i / M_i per row to `cm`, then inner iterations with
 // every lane busy; cm holds u_phase_split_cm_doubles(N, n_u) doubles, beta n_iter2 doubles (<= 6144)
 int64_t u_phase_split_cm_doubles(int64_t N, int n_u);
-hipError_t launch_u_phase_split(const double* V, const double* D, const double* Rtp, const double* alpha, double* u,
-                                double* u_prev, const SolverState* state, int64_t N, int S, int n_c, int n_u,
-                                int n_iter2, int mode, double* cm, double* beta, hipStream_t st);
+hipError_t launch_u_phase_split(const double* V, const double* D, const unsigned short* D16, int SD, const double* Rtp,
+                                const double* alpha, double* u, double* u_prev, const SolverState* state, int64_t N, int S,
+                                int n_c, int n_u, int n_iter2, int mode, double* cm, double* beta, hipStream_t st);
 
 // u phase for 9 <= n_u <= 26 unknown types on the matrix cores (dmf_kernels_rowpass_big.hip); Rtp = padded R_trunc
 bool u_phase_big_supported(int S, int n_c, int n_u, int n_iter2);

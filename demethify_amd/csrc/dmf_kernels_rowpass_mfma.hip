@@ -15,6 +15,7 @@
 //   C/D register r of lane l = C[(l >> 4) + 4 r][l & 15].
 // `Rt` here is the problem's padded copy of R_trunc: row stride 4 * NKC doubles, zero pad columns.
 #include <cstdlib>
+#include <type_traits>
 
 #include "dmf_device.h"
 #include "dmf_internal.h"
@@ -56,9 +57,12 @@ __device__ __forceinline__ double grad_row(double g, double base, const double (
 }
 
 // VEC: S % 4 == 0, so a lane's four samples are contiguous, 32-byte aligned and all in range.
-template <int NKC, int NU, bool VEC>
+// D16T (with VEC): the counts come from the problem's u16 copy (row stride SD) -- 8 instead of 32 bytes per lane and
+// strip, and 8 instead of 32 staging registers for the prefetched strips (with 7 or 8 unknowns the f64 form spills).
+template <int NKC, int NU, bool VEC, bool D16T>
 __global__ __launch_bounds__(512) void k_u_phase_mfma(
-    const double* __restrict__ V, const double* __restrict__ D, const double* __restrict__ Rt,
+    const double* __restrict__ V, const double* __restrict__ D, const unsigned short* __restrict__ D16, int SD,
+    const double* __restrict__ Rt,
     const double* __restrict__ alpha, double* __restrict__ u, double* __restrict__ u_prev,
     const SolverState* __restrict__ state, int64_t N, int S, int n_c, int n_iter2, int mode,
     double* __restrict__ cm_out) {
@@ -138,23 +142,40 @@ __global__ __launch_bounds__(512) void k_u_phase_mfma(
     const int64_t nblk = (N + 15) / 16;
     // Loads are unconditional from clamped addresses: out-of-range samples meet zero A operands and
     // out-of-range rows only feed output columns that are never read, so no masking is needed.
-    auto load_strip = [&](int64_t rowc, int t, v4d& e, v4d& d) {
+    using DStage = std::conditional_t<D16T, unsigned long long, v4d>;  // a strip's four counts as staged for the next block
+    auto load_strip = [&](int64_t rowc, int t, v4d& e, DStage& d) {
         const double* __restrict__ vp = V + rowc * S;
-        const double* __restrict__ dp = D + rowc * S;
-        if constexpr (VEC) {
+        if constexpr (D16T) {
+            static_assert(!D16T || VEC, "the u16 path reads four samples with one 8-byte load");
             const v2d v01 = *reinterpret_cast<const v2d*>(vp + col0[t]);
             const v2d v23 = *reinterpret_cast<const v2d*>(vp + col0[t] + 2);
-            const v2d d01 = *reinterpret_cast<const v2d*>(dp + col0[t]);
-            const v2d d23 = *reinterpret_cast<const v2d*>(dp + col0[t] + 2);
             e = v4d{v01.x, v01.y, v23.x, v23.y};
-            d = v4d{d01.x, d01.y, d23.x, d23.y};
+            d = *reinterpret_cast<const unsigned long long*>(D16 + rowc * SD + col0[t]);
         } else {
+            const double* __restrict__ dp = D + rowc * S;
+            if constexpr (VEC) {
+                const v2d v01 = *reinterpret_cast<const v2d*>(vp + col0[t]);
+                const v2d v23 = *reinterpret_cast<const v2d*>(vp + col0[t] + 2);
+                const v2d d01 = *reinterpret_cast<const v2d*>(dp + col0[t]);
+                const v2d d23 = *reinterpret_cast<const v2d*>(dp + col0[t] + 2);
+                e = v4d{v01.x, v01.y, v23.x, v23.y};
+                d = v4d{d01.x, d01.y, d23.x, d23.y};
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = col0[t] + r < S ? col0[t] + r : S - 1;
-                e[r] = vp[c];
-                d[r] = dp[c];
+                for (int r = 0; r < 4; ++r) {
+                    const int c = col0[t] + r < S ? col0[t] + r : S - 1;
+                    e[r] = vp[c];
+                    d[r] = dp[c];
+                }
             }
+        }
+    };
+    auto counts_of = [&](const DStage& d) -> v4d {
+        if constexpr (D16T) {
+            const unsigned int lo = (unsigned int)d, hi = (unsigned int)(d >> 32);
+            return v4d{(double)(lo & 0xFFFFu), (double)(lo >> 16), (double)(hi & 0xFFFFu), (double)(hi >> 16)};
+        } else {
+            return d;
         }
     };
     auto row_of = [&](int64_t blk) {
@@ -162,7 +183,8 @@ __global__ __launch_bounds__(512) void k_u_phase_mfma(
         return row < N ? row : N - 1;
     };
 
-    v4d nv[kStripsPerWave], nd[kStripsPerWave];
+    v4d nv[kStripsPerWave];
+    DStage nd[kStripsPerWave];
     double nrt[NKC > 0 ? NKC : 1];
     {
         const int64_t rowc = row_of(blockIdx.x);
@@ -204,7 +226,7 @@ __global__ __launch_bounds__(512) void k_u_phase_mfma(
 #pragma unroll
         for (int t = 0; t < kStripsPerWave; ++t) {
             v4d e = nv[t];
-            const v4d d = nd[t];
+            const v4d d = counts_of(nd[t]);
             load_strip(rowc_n, t, nv[t], nd[t]);  // prefetch the next row block's strip t ...
             __builtin_amdgcn_sched_barrier(0);    // ... and keep it in front of this strip's MFMAs
 #pragma unroll
@@ -288,9 +310,9 @@ bool u_phase_mfma_supported(int S, int n_c, int n_u) {
 }
 
 template <int NKC, int NU>
-static hipError_t launch_u_mfma_t(const double* V, const double* D, const double* Rt, const double* alpha,
-                                  double* u, double* u_prev, const SolverState* state, int64_t N, int S,
-                                  int n_c, int n_iter2, int mode, double* cm_out, hipStream_t st) {
+static hipError_t launch_u_mfma_t(const double* V, const double* D, const unsigned short* D16, int SD, const double* Rt,
+                                  const double* alpha, double* u, double* u_prev, const SolverState* state, int64_t N,
+                                  int S, int n_c, int n_iter2, int mode, double* cm_out, hipStream_t st) {
     constexpr int NV = NU + NU * (NU + 1) / 2;
     const int nstrips = (S + 15) / 16;
     const int NW = (nstrips + kStripsPerWave - 1) / kStripsPerWave;
@@ -298,11 +320,12 @@ static hipError_t launch_u_mfma_t(const double* V, const double* D, const double
     const size_t lds = ((size_t)(cm_out ? 0 : ((n_iter2 + 1) & ~1)) + (size_t)2 * NW * NV * 16) * sizeof(double);
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     const bool vec = (S & 3) == 0;
+    const bool d16 = vec && D16 != nullptr && (SD & 3) == 0;
+    const void* fn = d16   ? (const void*)k_u_phase_mfma<NKC, NU, true, true>
+                     : vec ? (const void*)k_u_phase_mfma<NKC, NU, true, false>
+                           : (const void*)k_u_phase_mfma<NKC, NU, false, false>;
     if (lds > 48 * 1024) {
-        hipError_t e = vec ? hipFuncSetAttribute((const void*)k_u_phase_mfma<NKC, NU, true>,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                           : hipFuncSetAttribute((const void*)k_u_phase_mfma<NKC, NU, false>,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int64_t nblk = (N + 15) / 16;
@@ -312,46 +335,50 @@ static hipError_t launch_u_mfma_t(const double* V, const double* D, const double
     if (const char* v = getenv("DMF_UMFMA_PER_CU")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (experiments)
     const int64_t cap = (int64_t)256 * per_cu;
     const int64_t grid = nblk < cap ? nblk : cap;
-    if (vec)
-        hipLaunchKernelGGL((k_u_phase_mfma<NKC, NU, true>), dim3((unsigned)grid), dim3(NW * 64), lds, st, V, D, Rt,
-                           alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out);
+    if (d16)
+        hipLaunchKernelGGL((k_u_phase_mfma<NKC, NU, true, true>), dim3((unsigned)grid), dim3(NW * 64), lds, st, V, D, D16, SD,
+                           Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out);
+    else if (vec)
+        hipLaunchKernelGGL((k_u_phase_mfma<NKC, NU, true, false>), dim3((unsigned)grid), dim3(NW * 64), lds, st, V, D, D16, SD,
+                           Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out);
     else
-        hipLaunchKernelGGL((k_u_phase_mfma<NKC, NU, false>), dim3((unsigned)grid), dim3(NW * 64), lds, st, V, D, Rt,
-                           alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out);
+        hipLaunchKernelGGL((k_u_phase_mfma<NKC, NU, false, false>), dim3((unsigned)grid), dim3(NW * 64), lds, st, V, D, D16,
+                           SD, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out);
     return hipGetLastError();
 }
 
 template <int NKC>
-static hipError_t launch_u_mfma_nkc(int n_u, const double* V, const double* D, const double* Rt,
-                                    const double* alpha, double* u, double* u_prev, const SolverState* state,
-                                    int64_t N, int S, int n_c, int n_iter2, int mode, double* cm_out,
-                                    hipStream_t st) {
+static hipError_t launch_u_mfma_nkc(int n_u, const double* V, const double* D, const unsigned short* D16, int SD,
+                                    const double* Rt, const double* alpha, double* u, double* u_prev,
+                                    const SolverState* state, int64_t N, int S, int n_c, int n_iter2, int mode,
+                                    double* cm_out, hipStream_t st) {
     switch (n_u) {
 #define DMF_CASE(NU_) \
-    case NU_: return launch_u_mfma_t<NKC, NU_>(V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
+    case NU_: return launch_u_mfma_t<NKC, NU_>(V, D, D16, SD, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
         DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4) DMF_CASE(5) DMF_CASE(6) DMF_CASE(7) DMF_CASE(8)
 #undef DMF_CASE
         default: return hipErrorInvalidValue;
     }
 }
 
-static hipError_t launch_u_phase_mfma_impl(const double* V, const double* D, const double* Rt, const double* alpha,
-                                           double* u, double* u_prev, const SolverState* state, int64_t N, int S,
-                                           int n_c, int n_u, int n_iter2, int mode, double* cm_out, hipStream_t st) {
+static hipError_t launch_u_phase_mfma_impl(const double* V, const double* D, const unsigned short* D16, int SD,
+                                           const double* Rt, const double* alpha, double* u, double* u_prev,
+                                           const SolverState* state, int64_t N, int S, int n_c, int n_u, int n_iter2,
+                                           int mode, double* cm_out, hipStream_t st) {
     switch ((n_c + 3) / 4) {
-        case 0: return launch_u_mfma_nkc<0>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
-        case 1: return launch_u_mfma_nkc<1>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
-        case 2: return launch_u_mfma_nkc<2>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
-        case 3: return launch_u_mfma_nkc<3>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
-        case 4: return launch_u_mfma_nkc<4>(n_u, V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
+        case 0: return launch_u_mfma_nkc<0>(n_u, V, D, D16, SD, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
+        case 1: return launch_u_mfma_nkc<1>(n_u, V, D, D16, SD, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
+        case 2: return launch_u_mfma_nkc<2>(n_u, V, D, D16, SD, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
+        case 3: return launch_u_mfma_nkc<3>(n_u, V, D, D16, SD, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
+        case 4: return launch_u_mfma_nkc<4>(n_u, V, D, D16, SD, Rt, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, cm_out, st);
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_u_phase_mfma(const double* V, const double* D, const double* Rt, const double* alpha,
-                               double* u, double* u_prev, const SolverState* state, int64_t N, int S, int n_c,
-                               int n_u, int n_iter2, int mode, hipStream_t st) {
-    return launch_u_phase_mfma_impl(V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_u, n_iter2, mode, nullptr, st);
+hipError_t launch_u_phase_mfma(const double* V, const double* D, const unsigned short* D16, int SD, const double* Rt,
+                               const double* alpha, double* u, double* u_prev, const SolverState* state, int64_t N, int S,
+                               int n_c, int n_u, int n_iter2, int mode, hipStream_t st) {
+    return launch_u_phase_mfma_impl(V, D, D16, SD, Rt, alpha, u, u_prev, state, N, S, n_c, n_u, n_iter2, mode, nullptr, st);
 }
 
 // ---- split mode for many inner steps (the CLI default under --purity is 500): c_i / M_i per row through HBM
@@ -479,11 +506,11 @@ __global__ __launch_bounds__(256) void k_u_inner_rows16(const double* __restrict
 int64_t u_phase_split_cm_doubles(int64_t N, int n_u) { return N * (n_u + (int64_t)n_u * (n_u + 1) / 2); }
 
 // cm: N x (n_u + NP) doubles, beta: n_iter2 doubles (both device scratch owned by the caller)
-hipError_t launch_u_phase_split(const double* V, const double* D, const double* Rt, const double* alpha, double* u,
-                                double* u_prev, const SolverState* state, int64_t N, int S, int n_c, int n_u,
-                                int n_iter2, int mode, double* cm, double* beta, hipStream_t st) {
+hipError_t launch_u_phase_split(const double* V, const double* D, const unsigned short* D16, int SD, const double* Rt,
+                                const double* alpha, double* u, double* u_prev, const SolverState* state, int64_t N, int S,
+                                int n_c, int n_u, int n_iter2, int mode, double* cm, double* beta, hipStream_t st) {
     if (cm == nullptr || beta == nullptr) return hipErrorInvalidValue;
-    hipError_t e = launch_u_phase_mfma_impl(V, D, Rt, alpha, u, u_prev, state, N, S, n_c, n_u, n_iter2, mode, cm, st);
+    hipError_t e = launch_u_phase_mfma_impl(V, D, D16, SD, Rt, alpha, u, u_prev, state, N, S, n_c, n_u, n_iter2, mode, cm, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_beta_table, dim3(1), dim3(1), 0, st, state, n_iter2, beta);
     const size_t lds = (size_t)(n_iter2 < kBetaChunk ? n_iter2 : kBetaChunk) * sizeof(double);
