@@ -13,7 +13,8 @@ import numpy as np
 from . import _lib as L
 from . import shard
 from .deconvolution import _init_unsupervised, cost_f_w, init_BSSMF_md, solve_problem
-from .device import Problem, get_context
+from .device import Problem, Solver, get_context
+from .staging import Prefetcher
 from .init_func import wls_intercept
 
 __all__ = ["compute_bic", "compute_aic", "compute_consensus_matrix", "compute_ccc", "run_deconvolution",
@@ -145,17 +146,36 @@ def evaluate_best_ic(meth_f, ref, counts, init_option, ic, seed, iter1, iter2, t
     mine = [order[i] for i in range(rank, len(order), world)]
     formula = compute_bic if ic == "BIC" else compute_aic
     local, keep = [], None  # keep = this rank's best candidate only (the reference keeps the running best, ic.py:212)
+
+    def draw(i):
+        # the candidate's initialisation (numpy's global generator: ONE worker thread), drawn while the GPU solves the
+        # candidate before it
+        n_u = n_u_values[i]
+        if ref is not None:
+            u0, _, a0 = init_BSSMF_md(init_option, meth_f, counts, ref, n_u, seed=seed, rb_alg=wls_intercept, _stack=False)
+        else:
+            u0, a0 = _init_unsupervised(init_option, meth_f, n_u, seed)
+        return u0, a0
+
+    mode = L.DMF_MODE_PARTIAL if ref is not None else L.DMF_MODE_UNSUPERVISED
     with Problem(get_context(), meth_f, counts, ref) as problem:
-        for i in mine:
-            n_u = n_u_values[i]
-            u, alpha = _solve(problem, meth_f, counts, ref, n_u, init_option, seed, iter1, iter2, tol)
-            cost = problem.cost(u, alpha)  # cost_f_w(meth_f, R, alpha, counts), ic.py:206
-            score = float(formula(cost, n_u, n_cpg, n_ct, n_samples))
-            local.append((i, score))
-            # strict '<' on the score, lowest candidate index among equal scores: what ic.py:212 does serially
-            # (a NaN score never wins, exactly as `ic_result < best_ic` upstream)
-            if score < (keep[0] if keep else float("inf")) or (keep and score == keep[0] and i < keep[1]):
-                keep = (score, i, u, alpha)
+        feed = Prefetcher(mine, draw, depth=1, workers=1)
+        try:
+            for i, (u0, a0) in feed:
+                n_u = n_u_values[i]
+                with Solver(problem, u0, a0, mode) as s:
+                    s.step(iter1, iter2, tol)
+                    cost = s.direct_cost()  # cost_f_w(meth_f, R, alpha, counts), ic.py:206, where the iterate lives
+                    score = float(formula(cost, n_u, n_cpg, n_ct, n_samples))
+                    local.append((i, score))
+                    # strict '<' on the score, lowest candidate index among equal scores: what ic.py:212 does serially
+                    # (a NaN score never wins, exactly as `ic_result < best_ic` upstream); only a candidate that becomes
+                    # this rank's best leaves the device
+                    if score < (keep[0] if keep else float("inf")) or (keep and score == keep[0] and i < keep[1]):
+                        u, alpha, _, _ = s.get()
+                        keep = (score, i, u, alpha)
+        finally:
+            feed.close()
     scores = [s for _, s in shard.gather_objects(local)]
     best_i, best_score = None, float("inf")
     for i, score in enumerate(scores):  # running strict minimum in candidate order, ic.py:212-216

@@ -14,3 +14,4 @@ timeout -k 10 100 tools/gram_i8_probe_ns >> gpurun_out/final/gram_i8_probe.txt 2
 timeout -k 10 200 python tools/restart_overheads.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/restart_overheads.txt
 du -sh gpurun_out/final
 DMF_BENCH_DEPTH=120 python bench.py --no-cpu-baseline --restarts 8 > gpurun_out/final/deep_coverage_bench_line.json 2> gpurun_out/final/deep.err
+timeout -k 10 400 python tools/ic_sweep_bench.py 50 2>&1 | grep -v amdgpu.ids > gpurun_out/final/ic_sweep.txt
