@@ -97,6 +97,7 @@ struct dmf_solver {
     bool use_gram_spec = false;
     bool use_gram_mfma = false;
     bool use_u_big = false;      // 9 <= n_u <= 26: matrix-core u phase with M_i in LDS
+    bool use_cm_i8 = false;      // 5 <= n_u <= 16 with u16 counts: split u phase, M_i on the integer matrix cores
     double* cm = nullptr;        // split u phase (many inner steps): per-row c_i / M_i, allocated on first use
     double* beta_tab = nullptr;  //   and the momentum coefficients of the inner steps
     int64_t beta_cap = 0;  // shapes beyond the lane-per-sample kernel's registers: MFMA Gram
@@ -405,6 +406,26 @@ int enqueue_u_phase(dmf_solver* s, int n_iter2) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
     FamilyScope scope(ctx, DMF_KERNEL_ROWPASS);
+    auto split_scratch = [&]() -> int {
+        if (s->cm == nullptr)
+            HIP_TRY(pool_alloc(ctx, (void**)&s->cm, (size_t)dmf::u_phase_split_cm_doubles(p->N, (int)s->n_u) * sizeof(double)));
+        if (s->beta_cap < n_iter2) {
+            pool_free(ctx, s->beta_tab);
+            s->beta_tab = nullptr;
+            HIP_TRY(pool_alloc(ctx, (void**)&s->beta_tab, (size_t)(n_iter2 > 0 ? n_iter2 : 1) * sizeof(double)));
+            s->beta_cap = n_iter2 > 0 ? n_iter2 : 1;
+        }
+        return DMF_OK;
+    };
+    if (s->use_cm_i8) {
+        // wide row groups on u16 counts: per-row c_i / M_i with M_i on the integer matrix cores, then the inner iterations
+        // chip-wide (dmf_kernels_cm_i8.hip)
+        DMF_TRY(split_scratch());
+        HIP_TRY(dmf::launch_u_phase_split_i8(p->V, p->D16, p->SD, p->ND, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N,
+                                             (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, s->cm, s->beta_tab,
+                                             ctx->stream));
+        return DMF_OK;
+    }
     if (s->use_u_big && dmf::u_phase_big_supported((int)p->S, (int)p->n_c, (int)s->n_u, n_iter2)) {
         HIP_TRY(dmf::launch_u_phase_big(p->V, p->D, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, (int)p->S,
                                         (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
@@ -421,14 +442,7 @@ int enqueue_u_phase(dmf_solver* s, int n_iter2) {
     }();
     if (s->u_path == 0 && (n_iter2 > kSplitInnerSteps || (int)s->n_u >= split_nu || (p->n_c > 0 && s->n_u >= 5))) {
         // many inner steps: one wave per workgroup running them is the bottleneck (see enqueue_outer_iteration)
-        if (s->cm == nullptr)
-            HIP_TRY(pool_alloc(ctx, (void**)&s->cm, (size_t)dmf::u_phase_split_cm_doubles(p->N, (int)s->n_u) * sizeof(double)));
-        if (s->beta_cap < n_iter2) {
-            pool_free(ctx, s->beta_tab);
-            s->beta_tab = nullptr;
-            HIP_TRY(pool_alloc(ctx, (void**)&s->beta_tab, (size_t)n_iter2 * sizeof(double)));
-            s->beta_cap = n_iter2;
-        }
+        DMF_TRY(split_scratch());
         HIP_TRY(dmf::launch_u_phase_split(p->V, p->D, p->D16, p->SD, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, (int)p->S,
                                           (int)p->n_c, (int)s->n_u, n_iter2, s->mode, s->cm, s->beta_tab, ctx->stream));
         return DMF_OK;
@@ -947,7 +961,13 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     s->use_gram_i8 = ctx->generic_level == 0 && p->ND > 0 && p->D16 != nullptr && known_ok &&
                      (n_c > 0 ? fp64_acc >= i8_min_features : n_c * n_u + n_u * (n_u + 1) / 2 >= 33) && n_u <= 20 &&
                      dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
-    if (s->use_v2) {
+    // Wide row groups (n_u 5..16) on u16 counts: the split u phase with the integer-matrix-core producer.  Measured at
+    // 5e5 x 128 against what ran before: see DESIGN.md section 5.  DMF_CM_I8_MIN_NU moves the lower end (experiments).
+    static const int cm_min_nu = [] { const char* v = getenv("DMF_CM_I8_MIN_NU"); return v != nullptr && atoi(v) > 0 ? atoi(v) : 5; }();
+    s->use_cm_i8 = ctx->generic_level == 0 && !s->use_v2 && p->ND > 0 && p->D16 != nullptr && n_u >= cm_min_nu && n_u <= 16 &&
+                   (n_c == 0 || (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 7) == 0)) &&
+                   dmf::cm_i8_supported(p->V, (int)S, (int)n_c, (int)n_u, p->ND, p->SD);
+    if (s->use_v2 || s->use_cm_i8) {
         // the row pass writes alpha_j alpha_l in fixed point on [0, 1]: true of every iterate (columns on the simplex),
         // checked for the caller's starting point
         std::vector<double> ha((size_t)K * S);
@@ -961,6 +981,7 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
         for (double a : ha)
             if (!(a >= 0.0 && a <= 1.0)) {
                 s->use_v2 = false;
+                s->use_cm_i8 = false;
                 break;
             }
     }
@@ -1178,7 +1199,8 @@ int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t
                  dmf::rowpass_fused_grid(n_full, S), (int)(p->N & 15));
         snprintf(gram, sizeof(gram), "fused");
     } else {
-        if (s->use_u_big && dmf::u_phase_big_supported(S, n_c, n_u, (int)n_iter2)) snprintf(row, sizeof(row), "k_u_phase_big");
+        if (s->use_cm_i8) snprintf(row, sizeof(row), "k_cm_i8<nd=%d>+k_u_inner_rows", p->ND);
+        else if (s->use_u_big && dmf::u_phase_big_supported(S, n_c, n_u, (int)n_iter2)) snprintf(row, sizeof(row), "k_u_phase_big");
         else if (s->u_path == 0 && (n_iter2 > kSplitInnerSteps || n_u >= 7 || (n_c > 0 && n_u >= 5)))
             snprintf(row, sizeof(row), "k_u_phase_mfma(split)+k_u_inner_rows");
         else if (s->u_path == 0) snprintf(row, sizeof(row), "k_u_phase_mfma");

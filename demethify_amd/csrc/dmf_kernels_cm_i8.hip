@@ -1,0 +1,357 @@
+// Per-row c_i / M_i of the split u phase for wide row groups (5 <= n_u <= 16), gfx950:
+//     c_i = alpha_unk (d_i * (v_i - Rt_i alpha_known))^T       FP64 matrix cores (as dmf_kernels_rowpass_mfma.hip)
+//     M_i[pair (j,l)] = sum_s (alpha_js alpha_ls) d_is          INTEGER matrix cores, exactly (as dmf_kernels_rowpass2.hip):
+// the counts are one or two balanced 8-bit digits, P = alpha_j alpha_l in [0, 1] seven digits of rint(P 2^52)
+// (dmf_fixedpoint.h); one v_mfma_i32_16x16x64_i8 per digit covers 16 rows x 64 samples x 16 pairs.  With n_u unknowns
+// there are n_u (n_u + 1) / 2 pairs (78 at 12): on the FP64 cores that product is 64 cycles per 16 x 4 x 16 piece and
+// was nine tenths of k_u_phase_mfma / k_u_phase_big; here it is 16 cycles per 16 x 64 x 16 piece and digit.
+//
+// Work split: a WAVE owns 32 CpG rows (two 16-row halves) and walks over ALL samples; nothing is exchanged between
+// waves after set-up (no barrier in the row loop, fixed summation order).  Per 16-row x 64-sample unit the wave
+//   * takes V (32 B per lane and 16-sample strip) and the u16 counts (8 B) in the "row-on-lane" layout
+//     lane = (row = l & 15, q = l >> 4), register r <-> sample s0 + 4 q + r, prefetched one unit ahead;
+//   * E^T = V^T - alpha_known^T Rt^T, c^T += alpha_unk (D*E)^T on v_mfma_f64_16x16x4 (A operands read from an LDS
+//     copy of alpha: a wave now meets every column group, so they no longer fit its registers);
+//   * packs the strip's four counts into one dword per digit plane -- the lane's 16 samples of the unit are exactly
+//     the 16 bytes of an i8 MFMA A operand (k <-> (q, strip, r)), no LDS round trip.
+// Then, per 16-pair tile: 7 (or 14) integer MFMAs per column group and row half against the P digits (B operands,
+// built once per workgroup in LDS in the same k order), the exact combine of dmf_kernels_rowpass2.hip, and the
+// row's M values go to HBM.  k_u_inner_rows16 runs the inner iterations from there.
+//
+// Layout facts used (tools/mfma_probe.hip): FP64 A[i][k]: lane (i = l & 15, k = l >> 4); B[k][j]: lane (k = l >> 4,
+// j = l & 15); C register r of lane l = C[(l >> 4) + 4 r][l & 15].  i8 16x16x64: A lane (row l & 15), B lane (column
+// l & 15), byte b of register g of lane-group l >> 4 is the same k on both sides; C register r = row 4 (l >> 4) + r.
+#include <cstdlib>
+
+#include "dmf_device.h"
+#include "dmf_fixedpoint.h"
+#include "dmf_internal.h"
+
+namespace dmf {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int kCmWaves = 8;  // waves per workgroup (they only share the LDS tables)
+
+struct CmLayout {
+    int AS;          // row stride of the alpha copy in doubles (64 ncg + 4)
+    int n_rows;      // 4 NKC (negated known rows, zero padded) + n_u
+    int pd_dwords4;  // P digit table: [ncg][nmt][7][64] x 16 bytes
+    size_t bytes;
+};
+
+__host__ __device__ inline CmLayout cm_layout(int S, int n_c, int n_u) {
+    CmLayout L;
+    const int ncg = (S + 63) / 64, nmt = (n_u * (n_u + 1) / 2 + 15) / 16;
+    L.AS = 64 * ncg + 4;
+    L.n_rows = (n_c + 3) / 4 * 4 + n_u;
+    L.pd_dwords4 = ncg * nmt * 7 * 64;
+    L.bytes = (size_t)L.pd_dwords4 * 16 + (size_t)L.n_rows * L.AS * sizeof(double);
+    return L;
+}
+
+// NKC = ceil(n_c / 4); ND = count digit planes (1: every count <= 127, 2: <= 32639); NCGX >= number of 64-sample
+// column groups (the per-group loops are unrolled NCGX times behind wave-uniform guards).
+template <int NKC, int ND, int NCGX>
+__global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, const unsigned short* __restrict__ D16, int SD,
+                                               const double* __restrict__ Rtp, const double* __restrict__ alpha,
+                                               const SolverState* __restrict__ state, int64_t N, int S, int n_c, int n_u,
+                                               double* __restrict__ cm_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (state->done) return;
+    constexpr int NWT = 7 + ND - 1;  // digit weights 256^0 .. 256^(NWT-1)
+    const int NP = n_u * (n_u + 1) / 2, NV = n_u + NP;
+    const int nmt = (NP + 15) / 16, ncg = (S + 63) / 64;
+    const CmLayout L = cm_layout(S, n_c, n_u);
+    v4i* __restrict__ pd = reinterpret_cast<v4i*>(lds_raw);
+    double* __restrict__ alds = reinterpret_cast<double*>(lds_raw + (size_t)L.pd_dwords4 * 16);
+    const int AS = L.AS;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int m16 = lane & 15, q = lane >> 4;
+
+    // ---- workgroup tables -------------------------------------------------------------------------------------
+    // alpha copy: rows 0 .. 4 NKC - 1 = -alpha_known (zero rows past n_c), then alpha_unk; zero for samples >= S
+    for (int i = threadIdx.x; i < L.n_rows * AS; i += kCmWaves * 64) {
+        const int r = i / AS, c = i - r * AS;
+        double val = 0.0;
+        if (c < S) {
+            if (r < 4 * NKC) val = r < n_c ? -alpha[(int64_t)r * S + c] : 0.0;
+            else val = alpha[(int64_t)(n_c + r - 4 * NKC) * S + c];
+        }
+        alds[i] = val;
+    }
+    // P digits: item (column group, pair tile) per wave; lane (pair m16, q), register g = strip, byte i:
+    // sample 64 cg + 16 g + 4 q + i  (the k order in which the row loop packs the counts)
+    for (int item = wave; item < ncg * nmt; item += kCmWaves) {
+        const int cg = item / nmt, mt = item - cg * nmt;
+        const int p = mt * 16 + m16;
+        int pl = 0;
+        while ((pl + 1) * (pl + 2) / 2 <= p) ++pl;
+        const int pj = p - pl * (pl + 1) / 2;
+        const bool pair_ok = p < NP;
+        v4i dg[7];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            unsigned int lo[4], hi[4], tl[4], th[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = 64 * cg + 16 * g + 4 * q + i;
+                const bool in = pair_ok && col < S;
+                const double aj = in ? alpha[(int64_t)(n_c + pj) * S + col] : 0.0;
+                const double al = in ? alpha[(int64_t)(n_c + pl) * S + col] : 0.0;
+                z_to_biased(aj, al, lo[i], hi[i]);
+            }
+            transpose4(lo, tl);
+            transpose4(hi, th);
+            dg[0][g] = (int)(tl[0] ^ 0x80808080u);
+            dg[1][g] = (int)(tl[1] ^ 0x80808080u);
+            dg[2][g] = (int)(tl[2] ^ 0x80808080u);
+            dg[3][g] = (int)(tl[3] ^ 0x80808080u);
+            dg[4][g] = (int)(th[0] ^ 0x80808080u);
+            dg[5][g] = (int)(th[1] ^ 0x80808080u);
+            dg[6][g] = (int)th[2];
+        }
+#pragma unroll
+        for (int t = 0; t < 7; ++t) pd[(item * 7 + t) * 64 + lane] = dg[t];
+    }
+    __syncthreads();
+
+    const int64_t nblk = (N + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * kCmWaves;
+    int64_t blk = (int64_t)blockIdx.x * kCmWaves + wave;
+    if (blk >= nblk) return;  // (no barrier below)
+
+    // row-on-lane addresses of a 16-row half: rows past N are clamped (their outputs are never stored)
+    auto row_of = [&](int64_t b, int h) {
+        const int64_t row = b * 32 + 16 * h + m16;
+        return row < N ? row : N - 1;
+    };
+    // strip t of column group cg: a lane's four samples start at c = 64 cg + 16 t + 4 q; S % 4 == 0, so they are all in
+    // range or all out -- out-of-range samples read V at column 0 (finite) against zero-padded counts
+    auto load_strip = [&](int64_t rowc, int cg, int t, v4d& e, unsigned long long& d) {
+        const int c = 64 * cg + 16 * t + 4 * q;
+        const double* __restrict__ vp = V + rowc * S + (c < S ? c : 0);
+        const v2d v01 = *reinterpret_cast<const v2d*>(vp);
+        const v2d v23 = *reinterpret_cast<const v2d*>(vp + 2);
+        e = v4d{v01.x, v01.y, v23.x, v23.y};
+        d = *reinterpret_cast<const unsigned long long*>(D16 + rowc * SD + c);
+    };
+
+    v4d nv[4];
+    unsigned long long nd[4];
+    double nrt[2][NKC > 0 ? NKC : 1];
+    {
+        const int64_t r0 = row_of(blk, 0), r1 = row_of(blk, 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) load_strip(r0, 0, t, nv[t], nd[t]);
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            nrt[0][kc] = Rtp[r0 * (4 * NKC) + kc * 4 + q];
+            nrt[1][kc] = Rtp[r1 * (4 * NKC) + kc * 4 + q];
+        }
+    }
+    const int m16c = m16 < n_u ? m16 : 0;  // (rows >= n_u of the c tile are never stored: any finite operand will do)
+    const double* __restrict__ a2row = alds + (4 * NKC + m16c) * AS + 4 * q;
+    const double* __restrict__ a1row = alds + q * AS + 4 * (m16 & 3) + (m16 >> 2);  // + 4 kc AS + 64 cg + 16 t
+
+    for (; blk < nblk; blk += stride) {
+        const int64_t nxt = blk + stride < nblk ? blk + stride : blk;
+        const int64_t rowh[2] = {row_of(blk, 0), row_of(blk, 1)};
+        const int64_t rown0 = row_of(nxt, 0);
+        double rtop[2][NKC > 0 ? NKC : 1];
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            rtop[0][kc] = nrt[0][kc];
+            rtop[1][kc] = nrt[1][kc];
+        }
+        if (NKC > 0) {
+            const int64_t rown1 = row_of(nxt, 1);
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) {
+                nrt[0][kc] = Rtp[rown0 * (4 * NKC) + kc * 4 + q];
+                nrt[1][kc] = Rtp[rown1 * (4 * NKC) + kc * 4 + q];
+            }
+        }
+        v4d cacc[2] = {v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}};
+        v4i cdig[2][NCGX][ND];  // count digit planes of this block: [row half][column group][plane], register = strip
+
+#pragma unroll
+        for (int cg = 0; cg < NCGX; ++cg) {
+            if (cg < ncg) {  // wave-uniform
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    // the unit after this one (same block: other half / next column group; else the next block's first)
+                    int64_t nrow;
+                    int ncgi;
+                    if (h == 0) {
+                        nrow = rowh[1];
+                        ncgi = cg;
+                    } else if (cg + 1 < ncg) {
+                        nrow = rowh[0];
+                        ncgi = cg + 1;
+                    } else {
+                        nrow = rown0;
+                        ncgi = 0;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        v4d e = nv[t];
+                        const unsigned long long dd = nd[t];
+                        load_strip(nrow, ncgi, t, nv[t], nd[t]);  // prefetch ...
+                        __builtin_amdgcn_sched_barrier(0);        // ... in front of this strip's MFMAs
+#pragma unroll
+                        for (int kc = 0; kc < NKC; ++kc) {
+                            const double a1 = a1row[4 * kc * AS + 64 * cg + 16 * t];
+                            e = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, rtop[h][kc], e, 0, 0, 0);
+                        }
+                        const unsigned int dl = (unsigned int)dd, dh = (unsigned int)(dd >> 32);
+                        const v4d d = {(double)(dl & 0xFFFFu), (double)(dl >> 16), (double)(dh & 0xFFFFu), (double)(dh >> 16)};
+                        const v4d w = d * e;
+                        const v2d a01 = *reinterpret_cast<const v2d*>(a2row + 64 * cg + 16 * t);
+                        const v2d a23 = *reinterpret_cast<const v2d*>(a2row + 64 * cg + 16 * t + 2);
+                        cacc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, w[0], cacc[h], 0, 0, 0);
+                        cacc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, w[1], cacc[h], 0, 0, 0);
+                        cacc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, w[2], cacc[h], 0, 0, 0);
+                        cacc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, w[3], cacc[h], 0, 0, 0);
+                        // the strip's four counts as bytes r = 0..3 of one dword per digit plane
+                        if constexpr (ND == 1) {
+                            cdig[h][cg][0][t] = (int)__builtin_amdgcn_perm(dh, dl, 0x06040200u);
+                        } else {
+                            // d = lo + 256 hi with lo in [-128, 127]: d + 128 = 256 hi + (lo + 128)
+                            const unsigned int xl = dl + 0x00800080u, xh = dh + 0x00800080u;
+                            cdig[h][cg][0][t] = (int)(__builtin_amdgcn_perm(xh, xl, 0x06040200u) ^ 0x80808080u);
+                            cdig[h][cg][1][t] = (int)__builtin_amdgcn_perm(xh, xl, 0x07050301u);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- c: C register r of lane l = c^T[unknown q + 4 r][row m16]
+        const int64_t row00 = blk * 32;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t row = row00 + 16 * h + m16;
+            if (row < N) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (q + 4 * r < n_u) cm_out[row * NV + q + 4 * r] = cacc[h][r];
+            }
+        }
+
+        // ---- M: per 16-pair tile, digit weight w = P digit + count plane; lane (pair m16, q) gets rows 4 q + r
+        // (HJ row halves share one read of the B operand; with four column groups the count planes leave registers
+        // for one half's accumulators only)
+        constexpr int HJ = NCGX <= 2 ? 2 : 1;
+        for (int mt = 0; mt < nmt; ++mt) {
+            const int p = mt * 16 + m16;
+#pragma unroll
+            for (int h0 = 0; h0 < 2; h0 += HJ) {
+                v4i acc[HJ][NWT];
+#pragma unroll
+                for (int h = 0; h < HJ; ++h)
+#pragma unroll
+                    for (int w = 0; w < NWT; ++w) acc[h][w] = v4i{0, 0, 0, 0};
+#pragma unroll
+                for (int cg = 0; cg < NCGX; ++cg) {
+                    if (cg < ncg) {
+                        const v4i* __restrict__ bp = pd + ((cg * nmt + mt) * 7) * 64 + lane;
+#pragma unroll
+                        for (int t = 0; t < 7; ++t) {
+                            const v4i b = bp[t * 64];
+#pragma unroll
+                            for (int h = 0; h < HJ; ++h) {
+                                acc[h][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(cdig[h0 + h][cg][0], b, acc[h][t], 0, 0, 0);
+                                if constexpr (ND == 2)
+                                    acc[h][t + 1] =
+                                        __builtin_amdgcn_mfma_i32_16x16x64_i8(cdig[h0 + h][cg][1], b, acc[h][t + 1], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+                // exact integer sum_w 256^w acc[w] in two halves that fit a double without rounding (|acc| < 2^24 per
+                // digit product sum at S <= 256 with two count planes), one rounding when they are joined
+#pragma unroll
+                for (int h = 0; h < HJ; ++h) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const double lo = fma(fma(fma((double)acc[h][3][rr], 256.0, (double)acc[h][2][rr]), 256.0, (double)acc[h][1][rr]),
+                                              256.0, (double)acc[h][0][rr]);
+                        double hi = fma(fma((double)acc[h][6][rr], 256.0, (double)acc[h][5][rr]), 256.0, (double)acc[h][4][rr]);
+                        if constexpr (ND == 2) hi = fma((double)acc[h][7][rr], 16777216.0, hi);
+                        const double m = fma(hi, 0x1p32, lo) * 0x1p-52;
+                        const int64_t row = row00 + 16 * (h0 + h) + 4 * q + rr;
+                        if (p < NP && row < N) cm_out[row * NV + n_u + p] = m;
+                    }
+                }
+            }
+        }
+    }
+}
+
+bool cm_i8_supported(const double* V, int S, int n_c, int n_u, int ND, int SD) {
+    if (n_u < 1 || n_u > 16 || n_c < 0 || n_c > 16) return false;
+    if (S < 4 || (S & 3) != 0 || S > 256 || (SD & 3) != 0 || SD < (S + 63) / 64 * 64) return false;
+    if (ND != 1 && ND != 2) return false;
+    if ((reinterpret_cast<uintptr_t>(V) & 15) != 0) return false;
+    return cm_layout(S, n_c, n_u).bytes <= 150 * 1024;
+}
+
+template <int NKC, int ND, int NCGX>
+static hipError_t launch_cm_t(const double* V, const unsigned short* D16, int SD, const double* Rtp, const double* alpha,
+                              const SolverState* state, int64_t N, int S, int n_c, int n_u, double* cm, hipStream_t st) {
+    const size_t lds = cm_layout(S, n_c, n_u).bytes;
+    static bool raised[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!raised[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_cm_i8<NKC, ND, NCGX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           150 * 1024);
+        if (e != hipSuccess) return e;
+        raised[dev] = true;
+    }
+    const int64_t nblk = (N + 31) / 32;
+    const int64_t want = (nblk + kCmWaves - 1) / kCmWaves;
+    // one workgroup (two waves per SIMD at ~200 registers) per CU, two where the tables leave room
+    int per_cu = lds <= 76 * 1024 ? 2 : 1;
+    if (const char* v = getenv("DMF_CM_PER_CU")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (experiments)
+    const int64_t cap = (int64_t)256 * per_cu;
+    const int64_t grid = want < cap ? want : cap;
+    hipLaunchKernelGGL((k_cm_i8<NKC, ND, NCGX>), dim3((unsigned)grid), dim3(kCmWaves * 64), lds, st, V, D16, SD, Rtp, alpha,
+                       state, N, S, n_c, n_u, cm);
+    return hipGetLastError();
+}
+
+template <int NKC>
+static hipError_t launch_cm_nkc(const double* V, const unsigned short* D16, int SD, int ND, const double* Rtp,
+                                const double* alpha, const SolverState* state, int64_t N, int S, int n_c, int n_u,
+                                double* cm, hipStream_t st) {
+    const bool wide = S > 128;
+    if (ND == 1)
+        return wide ? launch_cm_t<NKC, 1, 4>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, st)
+                    : launch_cm_t<NKC, 1, 2>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
+    return wide ? launch_cm_t<NKC, 2, 4>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, st)
+                : launch_cm_t<NKC, 2, 2>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
+}
+
+// cm: N x (n_u + n_u (n_u + 1) / 2) doubles.  Preconditions (cm_i8_supported + the caller): counts integral in
+// [0, 127] (ND = 1) or [0, 32639] (ND = 2) in D16 (row stride SD, zero padded to a multiple of 64 samples, rows to a
+// multiple of 16), alpha in [0, 1], Rtp = padded R_trunc (row stride 4 ceil(n_c / 4)).
+hipError_t launch_cm_i8(const double* V, const unsigned short* D16, int SD, int ND, const double* Rtp, const double* alpha,
+                        const SolverState* state, int64_t N, int S, int n_c, int n_u, double* cm, hipStream_t st) {
+    if (!cm_i8_supported(V, S, n_c, n_u, ND, SD) || cm == nullptr || D16 == nullptr) return hipErrorInvalidValue;
+    switch ((n_c + 3) / 4) {
+        case 0: return launch_cm_nkc<0>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
+        case 1: return launch_cm_nkc<1>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
+        case 2: return launch_cm_nkc<2>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
+        case 3: return launch_cm_nkc<3>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
+        case 4: return launch_cm_nkc<4>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace dmf

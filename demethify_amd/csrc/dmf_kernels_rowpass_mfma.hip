@@ -505,13 +505,9 @@ __global__ __launch_bounds__(256) void k_u_inner_rows16(const double* __restrict
 
 int64_t u_phase_split_cm_doubles(int64_t N, int n_u) { return N * (n_u + (int64_t)n_u * (n_u + 1) / 2); }
 
-// cm: N x (n_u + NP) doubles, beta: n_iter2 doubles (both device scratch owned by the caller)
-hipError_t launch_u_phase_split(const double* V, const double* D, const unsigned short* D16, int SD, const double* Rt,
-                                const double* alpha, double* u, double* u_prev, const SolverState* state, int64_t N, int S,
-                                int n_c, int n_u, int n_iter2, int mode, double* cm, double* beta, hipStream_t st) {
-    if (cm == nullptr || beta == nullptr) return hipErrorInvalidValue;
-    hipError_t e = launch_u_phase_mfma_impl(V, D, D16, SD, Rt, alpha, u, u_prev, state, N, S, n_c, n_u, n_iter2, mode, cm, st);
-    if (e != hipSuccess) return e;
+// the inner iterations from cm (N x (n_u + NP) doubles); beta: n_iter2 doubles of device scratch
+static hipError_t launch_u_inner(const double* cm, double* beta, double* u, double* u_prev, const SolverState* state,
+                                 int64_t N, int n_u, int n_iter2, int mode, hipStream_t st) {
     hipLaunchKernelGGL(k_beta_table, dim3(1), dim3(1), 0, st, state, n_iter2, beta);
     const size_t lds = (size_t)(n_iter2 < kBetaChunk ? n_iter2 : kBetaChunk) * sizeof(double);
 #define DMF_CASE(NU_)                                                                                          \
@@ -531,10 +527,33 @@ hipError_t launch_u_phase_split(const double* V, const double* D, const unsigned
     }
     switch (n_u) {
         DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4) DMF_CASE16(5) DMF_CASE16(6) DMF_CASE16(7) DMF_CASE16(8)
+        DMF_CASE16(9) DMF_CASE16(10) DMF_CASE16(11) DMF_CASE16(12) DMF_CASE16(13) DMF_CASE16(14) DMF_CASE16(15) DMF_CASE16(16)
         default: return hipErrorInvalidValue;
     }
 #undef DMF_CASE
+#undef DMF_CASE16
     return hipGetLastError();
+}
+
+// cm: N x (n_u + NP) doubles, beta: n_iter2 doubles (both device scratch owned by the caller)
+hipError_t launch_u_phase_split(const double* V, const double* D, const unsigned short* D16, int SD, const double* Rt,
+                                const double* alpha, double* u, double* u_prev, const SolverState* state, int64_t N, int S,
+                                int n_c, int n_u, int n_iter2, int mode, double* cm, double* beta, hipStream_t st) {
+    if (cm == nullptr || beta == nullptr) return hipErrorInvalidValue;
+    hipError_t e = launch_u_phase_mfma_impl(V, D, D16, SD, Rt, alpha, u, u_prev, state, N, S, n_c, n_u, n_iter2, mode, cm, st);
+    if (e != hipSuccess) return e;
+    return launch_u_inner(cm, beta, u, u_prev, state, N, n_u, n_iter2, mode, st);
+}
+
+// the same with the integer-matrix-core producer of dmf_kernels_cm_i8.hip (n_u <= 16; its preconditions are the caller's)
+hipError_t launch_u_phase_split_i8(const double* V, const unsigned short* D16, int SD, int ND, const double* Rt,
+                                   const double* alpha, double* u, double* u_prev, const SolverState* state, int64_t N,
+                                   int S, int n_c, int n_u, int n_iter2, int mode, double* cm, double* beta,
+                                   hipStream_t st) {
+    if (cm == nullptr || beta == nullptr) return hipErrorInvalidValue;
+    hipError_t e = launch_cm_i8(V, D16, SD, ND, Rt, alpha, state, N, S, n_c, n_u, cm, st);
+    if (e != hipSuccess) return e;
+    return launch_u_inner(cm, beta, u, u_prev, state, N, n_u, n_iter2, mode, st);
 }
 
 }  // namespace dmf

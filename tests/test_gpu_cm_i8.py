@@ -1,0 +1,87 @@
+"""Oracle parity of the wide-row-group u phase (5 <= n_u <= 16 on u16 counts): k_cm_i8 (c_i on the FP64 matrix cores,
+M_i exactly on the integer matrix cores, a wave per 32 CpG rows) + k_u_inner_rows16.
+
+Every case asserts (Solver.describe) that it enters that producer; the update_u known-answer cases compare one u phase
+with non-initial momentum against the oracle's update_u (deconvolution.py:80-90)."""
+import numpy as np
+import pytest
+
+from oracle import solver as osol
+
+from conftest import rel_err
+from test_gpu_bench_paths import _oracle, _solve_at_level
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 1e-8
+
+# (N, S, n_c, n_u, T1, depth, why)
+CM_CASES = [
+    (2000, 128, 0, 8, 3, 40, "config 5's shape class: no known types, 36 pairs = 3 tiles, two column groups"),
+    (1500, 128, 0, 12, 3, 40, "78 pairs = 5 tiles (was k_u_phase_big)"),
+    (1000, 64, 0, 16, 2, 40, "136 pairs = 9 tiles, one column group, c tile full"),
+    (1031, 128, 12, 6, 3, 40, "NKC = 3 known-type chain, last block 7 rows (second half empty)"),
+    (33, 4, 2, 5, 3, 40, "S = 4: one strip in range, 60 samples of the column group padded; 33 rows = one full block + 1"),
+    (47, 132, 5, 9, 3, 40, "S = 4 mod 64 -> ragged third column group (NCGX = 4 instantiation), n_c not a multiple of 4"),
+    (2100, 256, 16, 7, 2, 60, "four column groups (row halves in turn in the M stage), NKC = 4"),
+    (1800, 200, 3, 10, 2, 60, "ragged fourth column group, 55 pairs"),
+    (1200, 128, 4, 8, 3, 3000, "two count digit planes (counts above 127)"),
+    (900, 256, 0, 8, 2, 2500, "two count digit planes, four column groups"),
+    (5000, 64, 1, 5, 3, 40, "several blocks per wave? no: 157 blocks over 8-wave workgroups, ragged last block"),
+]
+
+
+@pytest.mark.parametrize("N,S,n_c,n_u,T1,depth,why", CM_CASES)
+def test_cm_i8_shapes_against_oracle(ctx, N, S, n_c, n_u, T1, depth, why):
+    from demethify_amd import _lib as L
+
+    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=23, depth=depth)
+    D[::5, ::3] = 0  # zero coverage (what --fillna produces)
+    V = np.where(D == 0, 0.0, V)
+    u0, a0, wu, wa = _oracle(V, D, Rt, n_c, n_u, T1, seed=3)
+    mode = L.DMF_MODE_PARTIAL if n_c else L.DMF_MODE_UNSUPERVISED
+    nd = 1 if D.max() <= 127 else 2
+    u, alpha, cost, direct, _ = _solve_at_level(ctx, 0, V, D, Rt if n_c else None, u0, a0, mode, T1,
+                                                [f"rowpass=k_cm_i8<nd={nd}>+k_u_inner_rows"])
+    assert rel_err(alpha, wa) < TIGHT and np.abs(alpha - wa).max() < TIGHT, why
+    assert np.abs(u - wu).max() < TIGHT, why
+    want = osol.weighted_cost(V, np.c_[Rt, wu] if n_c else wu, wa, D)
+    assert cost == pytest.approx(want, rel=1e-9) and direct == pytest.approx(want, rel=1e-11)
+
+
+def test_cm_i8_many_blocks_per_wave(ctx):
+    """More 32-row blocks than the grid has waves (the persistent loop, the next-block prefetch and the R_trunc row
+    hand-over are entered), compared with the first-generation kernels on the same start."""
+    from demethify_amd import _lib as L
+
+    N, S, n_c, n_u = 32 * 8 * 256 * 2 + 32 * 5 + 3, 64, 4, 6
+    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=5, depth=30)
+    rs = np.random.RandomState(7)
+    u0 = rs.uniform(size=(N, n_u))
+    a0 = rs.dirichlet(np.ones(n_c + n_u), S).T
+    u_new, a_new, c_new, d_new, _ = _solve_at_level(ctx, 0, V, D, Rt, u0, a0, L.DMF_MODE_PARTIAL, 3, ["rowpass=k_cm_i8<nd=1>"])
+    u_old, a_old, c_old, d_old, _ = _solve_at_level(ctx, 3, V, D, Rt, u0, a0, L.DMF_MODE_PARTIAL, 3, ["rowpass=k_u_phase_mfma"])
+    assert np.abs(u_new - u_old).max() < 1e-10 and np.abs(a_new - a_old).max() < 1e-10
+    assert d_new == pytest.approx(d_old, rel=1e-11)
+
+
+@pytest.mark.parametrize("n_c,n_u", [(0, 9), (6, 5), (2, 14)])
+def test_update_u_known_answer_on_cm_i8(ctx, n_c, n_u):
+    """One u phase from a NON-initial momentum state through dmf_update_u against the oracle's u_phase."""
+    from demethify_amd.device import Problem
+
+    N, S = 700, 128
+    V, D, Rt = osol.synthetic_problem(N, S, max(n_c, 1), n_u, seed=41, depth=50)
+    if n_c == 0:
+        Rt = np.zeros((N, 0))
+    rs = np.random.RandomState(9)
+    u, u_prev = rs.uniform(size=(N, n_u)), rs.uniform(size=(N, n_u))
+    alpha = rs.dirichlet(np.ones(n_c + n_u), S).T
+    d = float(D.max()) ** 2
+    l_w = np.linalg.norm(alpha[-n_u:]) ** 2 * d
+    a1, l_w_prev = 1.7, 0.9 * l_w
+    want = osol.u_phase(u, alpha, 20, a1, l_w_prev, l_w, u_prev, V, Rt, n_u, D)
+    with Problem(ctx, V, D, Rt if n_c else None) as p:
+        got = p.update_u(u, u_prev, alpha, 20, a1, l_w_prev, l_w)
+    assert np.abs(got[0] - want[0]).max() < 1e-11 and np.abs(got[1] - want[1]).max() < 1e-11
+    assert got[2] == pytest.approx(want[2], rel=1e-15) and got[3] == want[3]
