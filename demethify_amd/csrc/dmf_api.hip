@@ -402,25 +402,29 @@ int check_ctx(dmf_context* ctx) {
 
 constexpr int kSplitInnerSteps = 50;  // beyond this the unfused / split u phase beats the fused kernel
 
+// scratch of the split u phase: per-row c_i / M_i and the momentum coefficients of the inner steps (allocated on first use)
+int ensure_split_scratch(dmf_solver* s, int n_iter2) {
+    dmf_context* ctx = s->ctx;
+    const dmf_problem* p = s->p;
+    if (s->cm == nullptr)
+        HIP_TRY(pool_alloc(ctx, (void**)&s->cm, (size_t)dmf::u_phase_split_cm_doubles(p->N, (int)s->n_u) * sizeof(double)));
+    if (s->beta_cap < n_iter2 || s->beta_tab == nullptr) {
+        pool_free(ctx, s->beta_tab);
+        s->beta_tab = nullptr;
+        HIP_TRY(pool_alloc(ctx, (void**)&s->beta_tab, (size_t)(n_iter2 > 0 ? n_iter2 : 1) * sizeof(double)));
+        s->beta_cap = n_iter2 > 0 ? n_iter2 : 1;
+    }
+    return DMF_OK;
+}
+
 int enqueue_u_phase(dmf_solver* s, int n_iter2) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
     FamilyScope scope(ctx, DMF_KERNEL_ROWPASS);
-    auto split_scratch = [&]() -> int {
-        if (s->cm == nullptr)
-            HIP_TRY(pool_alloc(ctx, (void**)&s->cm, (size_t)dmf::u_phase_split_cm_doubles(p->N, (int)s->n_u) * sizeof(double)));
-        if (s->beta_cap < n_iter2) {
-            pool_free(ctx, s->beta_tab);
-            s->beta_tab = nullptr;
-            HIP_TRY(pool_alloc(ctx, (void**)&s->beta_tab, (size_t)(n_iter2 > 0 ? n_iter2 : 1) * sizeof(double)));
-            s->beta_cap = n_iter2 > 0 ? n_iter2 : 1;
-        }
-        return DMF_OK;
-    };
     if (s->use_cm_i8) {
         // wide row groups on u16 counts: per-row c_i / M_i with M_i on the integer matrix cores, then the inner iterations
         // chip-wide (dmf_kernels_cm_i8.hip)
-        DMF_TRY(split_scratch());
+        DMF_TRY(ensure_split_scratch(s, n_iter2));
         HIP_TRY(dmf::launch_u_phase_split_i8(p->V, p->D16, p->SD, p->ND, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N,
                                              (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, s->cm, s->beta_tab,
                                              ctx->stream));
@@ -442,7 +446,7 @@ int enqueue_u_phase(dmf_solver* s, int n_iter2) {
     }();
     if (s->u_path == 0 && (n_iter2 > kSplitInnerSteps || (int)s->n_u >= split_nu || (p->n_c > 0 && s->n_u >= 5))) {
         // many inner steps: one wave per workgroup running them is the bottleneck (see enqueue_outer_iteration)
-        DMF_TRY(split_scratch());
+        DMF_TRY(ensure_split_scratch(s, n_iter2));
         HIP_TRY(dmf::launch_u_phase_split(p->V, p->D, p->D16, p->SD, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, (int)p->S,
                                           (int)p->n_c, (int)s->n_u, n_iter2, s->mode, s->cm, s->beta_tab, ctx->stream));
         return DMF_OK;
@@ -539,6 +543,30 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
             FamilyScope scope(ctx, DMF_KERNEL_ROWPASS);
             HIP_TRY(dmf::launch_rowpass_v2(p->V, p->D16, p->SD, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, S,
                                            n_c, n_u, n_iter2, s->mode, p->ND, s->slab, s->u2_partials, &grid, ctx->stream));
+        }
+        {
+            FamilyScope scope(ctx, DMF_KERNEL_GRAM);
+            HIP_TRY(dmf::launch_gram_i8(p->Dt8, p->plane_stride, p->SD, p->ND, p->Rtp, s->u, p->N, n_c, n_u, s->job_k,
+                                        s->job_l, nf, s->slab_i8, s->slab_i8_words, &s->state->done, &ny, ctx->stream));
+            HIP_TRY(dmf::launch_gram_v2_reduce(s->slab_i8, ny, nf, p->SD, s->slab, grid, n_u, S, s->acc_i8, s->job_dst,
+                                               s->gb, &s->state->done, s->u2_partials, grid, s->state, ctx->stream));
+        }
+        DMF_TRY(enqueue_alpha_phase(s, n_iter2));
+        return DMF_OK;
+    }
+    if (s->use_cm_i8 && s->use_gram_i8 &&
+        dmf::u_inner_bu_supported(p->V, (int)p->S, p->SD, (int)s->n_u, n_iter2)) {
+        // Wide row groups on u16 counts: c_i / M_i (M_i on the integer matrix cores), then the inner iterations fused with
+        // the b_u stream and the ||u||^2 shares, then the integer Gram and its reduce -- four launches + the momentum table.
+        const int S = (int)p->S, n_c = (int)p->n_c, n_u = (int)s->n_u;
+        const int nf = n_c * n_u + n_u * (n_u + 1) / 2;
+        int grid = 0, ny = 0;
+        DMF_TRY(ensure_split_scratch(s, n_iter2));
+        {
+            FamilyScope scope(ctx, DMF_KERNEL_ROWPASS);
+            HIP_TRY(dmf::launch_u_phase_split_i8_bu(p->V, p->D16, p->SD, p->ND, p->Rtp, s->alpha, s->u, s->u_prev, s->state,
+                                                    p->N, S, n_c, n_u, n_iter2, s->mode, s->cm, s->beta_tab, s->slab,
+                                                    s->u2_partials, &grid, ctx->stream));
         }
         {
             FamilyScope scope(ctx, DMF_KERNEL_GRAM);
@@ -954,10 +982,9 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     // accumulators on.  DMF_GRAM_I8_MIN moves the threshold (experiments).
     static const int i8_min_features = [] { const char* v = getenv("DMF_GRAM_I8_MIN"); return v != nullptr ? atoi(v) : 48; }();
     const int fp64_acc = (int)((n_c + 3) / 4 * 4 * n_u + n_u * (n_u + 1) / 2 + n_u);
-    static const bool i8_nc0 = [] { const char* v = getenv("DMF_GRAM_I8_NC0"); return v != nullptr && v[0] == '1'; }();  // (experiments)
-    // (without known types the integer route pays only at exactly 8 unknowns -- 36 features: 0.24 -> 0.20 ms; 9 and more
-    // are equal to k_gram_u: DMF_GRAM_I8_NC0=1 forces it for experiments)
-    const bool known_ok = n_c > 0 ? (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0) : (i8_nc0 || n_u <= 8);
+    // (without known types: from 8 unknowns -- 36 features -- on.  At 5e5 x 128 with k_bu_cols2 up to 16 unknowns:
+    // 0+8 0.24 -> 0.20 ms, 0+12 0.36 -> 0.29, 0+16 0.67 (k_gram_mfma) -> 0.36; below 8 k_gram_u is cheaper.)
+    const bool known_ok = n_c > 0 ? (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0) : true;
     s->use_gram_i8 = ctx->generic_level == 0 && p->ND > 0 && p->D16 != nullptr && known_ok &&
                      (n_c > 0 ? fp64_acc >= i8_min_features : n_c * n_u + n_u * (n_u + 1) / 2 >= 33) && n_u <= 20 &&
                      dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
@@ -1025,6 +1052,10 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     if (s->use_gram_i8) {
         const int64_t bu = (int64_t)dmf::bu_cols_grid(N) * n_u * S;
         if (bu > s->slab_doubles) s->slab_doubles = bu;
+        if (s->use_cm_i8) {  // k_inner_bu writes one slab per workgroup
+            const int64_t bu2 = (int64_t)dmf::u_inner_bu_grid(N, (int)S) * n_u * S;
+            if (bu2 > s->slab_doubles) s->slab_doubles = bu2;
+        }
     }
     const size_t un = (size_t)N * n_u * sizeof(double), an = (size_t)K * S * sizeof(double);
     const size_t un_alloc = (un + 15) & ~(size_t)15;  // the integer Gram kernel fetches u in 16-byte pieces
@@ -1199,14 +1230,18 @@ int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t
                  dmf::rowpass_fused_grid(n_full, S), (int)(p->N & 15));
         snprintf(gram, sizeof(gram), "fused");
     } else {
-        if (s->use_cm_i8) snprintf(row, sizeof(row), "k_cm_i8<nd=%d>+k_u_inner_rows", p->ND);
+        if (s->use_cm_i8 && s->use_gram_i8 && dmf::u_inner_bu_supported(p->V, S, p->SD, n_u, (int)n_iter2))
+            snprintf(row, sizeof(row), "k_cm_i8<nd=%d>+k_inner_bu", p->ND);
+        else if (s->use_cm_i8) snprintf(row, sizeof(row), "k_cm_i8<nd=%d>+k_u_inner_rows", p->ND);
         else if (s->use_u_big && dmf::u_phase_big_supported(S, n_c, n_u, (int)n_iter2)) snprintf(row, sizeof(row), "k_u_phase_big");
         else if (s->u_path == 0 && (n_iter2 > kSplitInnerSteps || n_u >= 7 || (n_c > 0 && n_u >= 5)))
             snprintf(row, sizeof(row), "k_u_phase_mfma(split)+k_u_inner_rows");
         else if (s->u_path == 0) snprintf(row, sizeof(row), "k_u_phase_mfma");
         else if (s->u_path == 1) snprintf(row, sizeof(row), "k_u_phase_gram");
         else snprintf(row, sizeof(row), "k_u_step_direct");
-        if (s->use_gram_i8)
+        if (s->use_gram_i8 && s->use_cm_i8 && dmf::u_inner_bu_supported(p->V, S, p->SD, n_u, (int)n_iter2))
+            snprintf(gram, sizeof(gram), "k_gram_i8<nd=%d>/w8", p->ND);  // (b_u comes from k_inner_bu)
+        else if (s->use_gram_i8)
             snprintf(gram, sizeof(gram), "k_bu_cols+k_gram_i8<nd=%d>/w8", p->ND);
         else snprintf(gram, sizeof(gram), "%s", s->use_gram_spec ? "k_gram_u" : s->use_gram_mfma ? "k_gram_mfma" : "k_gram");
     }

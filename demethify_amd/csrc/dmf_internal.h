@@ -163,6 +163,15 @@ hipError_t launch_u_phase_split_i8(const double* V, const unsigned short* D16, i
                                    int S, int n_c, int n_u, int n_iter2, int mode, double* cm, double* beta,
                                    hipStream_t st);
 
+// ... and with the inner iterations fused with the b_u stream of the integer Gram route (k_inner_bu): slab holds
+// u_inner_bu_grid(N, S) x n_u x S doubles, u2_partials one double per workgroup (their count comes back in grid_out)
+bool u_inner_bu_supported(const double* V, int S, int SD, int n_u, int n_iter2);
+int u_inner_bu_grid(int64_t N, int S);
+hipError_t launch_u_phase_split_i8_bu(const double* V, const unsigned short* D16, int SD, int ND, const double* Rtp,
+                                      const double* alpha, double* u, double* u_prev, const SolverState* state, int64_t N,
+                                      int S, int n_c, int n_u, int n_iter2, int mode, double* cm, double* beta,
+                                      double* slab, double* u2_partials, int* grid_out, hipStream_t st);
+
 // u phase for 9 <= n_u <= 26 unknown types on the matrix cores (dmf_kernels_rowpass_big.hip); Rtp = padded R_trunc
 bool u_phase_big_supported(int S, int n_c, int n_u, int n_iter2);
 hipError_t launch_u_phase_big(const double* V, const double* D, const double* Rtp, const double* alpha, double* u,

@@ -298,7 +298,7 @@ bool cm_i8_supported(const double* V, int S, int n_c, int n_u, int ND, int SD) {
     if (S < 4 || (S & 3) != 0 || S > 256 || (SD & 3) != 0 || SD < (S + 63) / 64 * 64) return false;
     if (ND != 1 && ND != 2) return false;
     if ((reinterpret_cast<uintptr_t>(V) & 15) != 0) return false;
-    return cm_layout(S, n_c, n_u).bytes <= 150 * 1024;
+    return cm_layout(S, n_c, n_u).bytes <= 160 * 1024;
 }
 
 template <int NKC, int ND, int NCGX>
@@ -310,7 +310,7 @@ static hipError_t launch_cm_t(const double* V, const unsigned short* D16, int SD
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!raised[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)k_cm_i8<NKC, ND, NCGX>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           150 * 1024);
+                                           160 * 1024);
         if (e != hipSuccess) return e;
         raised[dev] = true;
     }

@@ -37,7 +37,7 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 namespace {
 constexpr int kNSL = 7;       // balanced base-256 digits of rint(z 2^52)
 constexpr int kRing = 8;      // LDS-DMA ring: block slots
-constexpr int kMaxFeat = 96;
+constexpr int kMaxFeat = 256;  // (64 per launch)
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ builders
@@ -600,12 +600,13 @@ hipError_t launch_bu_cols(const double* V, const unsigned short* D16, int SD, co
     const int nbx = bu_cols_grid(N);
     *n_slabs_out = nbx;
     const dim3 block(256);
-    if ((S & 1) == 0 && (SD & 1) == 0 && S >= 128 && n_u <= 10 && (reinterpret_cast<uintptr_t>(V) & 15) == 0) {
+    if ((S & 1) == 0 && (SD & 1) == 0 && S >= 128 && n_u <= 16 && (reinterpret_cast<uintptr_t>(V) & 15) == 0) {
         const dim3 grid2(nbx, (S + 127) / 128);
-        switch (n_u) {  // (LDS for the cross-wave sum: 3 x NU x 2 x 64 doubles <= 30 KB up to ten unknowns)
+        switch (n_u) {  // (LDS for the cross-wave sum: 3 x NU x 2 x 64 doubles = 48 KB at sixteen unknowns)
 #define DMF_CASE2(NU_) \
     case NU_: hipLaunchKernelGGL((k_bu_cols2<NU_>), grid2, block, 0, st, V, D16, SD, u, N, S, slab, done_flag); return hipGetLastError();
             DMF_CASE2(1) DMF_CASE2(2) DMF_CASE2(3) DMF_CASE2(4) DMF_CASE2(5) DMF_CASE2(6) DMF_CASE2(7) DMF_CASE2(8) DMF_CASE2(9) DMF_CASE2(10)
+            DMF_CASE2(11) DMF_CASE2(12) DMF_CASE2(13) DMF_CASE2(14) DMF_CASE2(15) DMF_CASE2(16)
 #undef DMF_CASE2
             default: break;
         }
@@ -766,7 +767,8 @@ void gram_i8_geometry(int64_t N, int SD, int* nsh, int* ny, int64_t* rows_per_wg
 
 bool gram_i8_supported(int n_c, int n_u, int ND, int64_t N, int SD) {
     const int nf = n_c * n_u + n_u * (n_u + 1) / 2;
-    if (n_c + n_u > 20 || nf < 1 || nf > kMaxFeat || ND < 1 || ND > 2) return false;
+    // (a block's x image -- 32 rows of the padded R_trunc copy and of u -- is fetched as at most two 4-KB pieces)
+    if ((n_c + 3) / 4 * 4 + n_u > 32 || n_u > 20 || nf < 1 || nf > kMaxFeat || ND < 1 || ND > 2) return false;
     int nsh, ny;
     int64_t rpw;
     gram_i8_geometry(N, SD, &nsh, &ny, &rpw);

@@ -445,11 +445,18 @@ __global__ __launch_bounds__(256) void k_u_inner_rows(const double* __restrict__
 // needs lane l's value in every lane of the row, which v_fmac_f64_dpp row_newbcast:l delivers inside the multiply-add --
 // NU instructions per step where the group form above pays 2 NU ds_bpermute round trips (k_u_inner_rows<8>: 239 us at
 // 5e5 rows and 20 steps; this form: see DESIGN.md).  Same per-row arithmetic order: g = c_j - sum_l M_jl x_l, l ascending.
+// (a DPP source written by the previous vector instruction needs two wait states: only the first multiply-add of a
+// gradient follows the instruction that produced x)
 template <int L>
 __device__ __forceinline__ void fmac_row16(double& acc, double x, double m) {
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                 : "+v"(acc)
-                 : "v"(x), "v"(m), "n"(L));
+    if constexpr (L == 0)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc)
+                     : "v"(x), "v"(m), "n"(L));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc)
+                     : "v"(x), "v"(m), "n"(L));
 }
 template <int NU, int L = 0>
 __device__ __forceinline__ void grad_row16(double& g, double base, const double (&Mneg)[NU]) {
@@ -503,6 +510,197 @@ __global__ __launch_bounds__(256) void k_u_inner_rows16(const double* __restrict
     }
 }
 
+// The inner iterations AND b_u = u^T (D * V) of the rows just finished, in one launch (wide row groups on u16 counts; the
+// integer Gram route needs b_u from a stream over V and the counts, k_bu_cols2 as a kernel of its own).  The inner
+// iterations are a chain of dependent FP64 instructions with next to no memory traffic, the b_u stream is all memory
+// traffic: a workgroup alternates between them on chunks of 16 NSG CpG rows --
+//   * all loads of the chunk are issued up front: the rows' c / M (lane = (row, unknown), one row per DPP row as in
+//     k_u_inner_rows16, four rows per wave), then the V / count pieces of the b_u stream (lane = two adjacent samples,
+//     4 NSG rows per wave), which land while the chains run;
+//   * the finished rows go to HBM and into an LDS tile (double buffered: one barrier per chunk);
+//   * b_u accumulates per lane over all chunks of the (persistent) workgroup, is summed over the waves at the end and
+//     written as one slab per workgroup (layout of k_bu_cols2); the workgroup's share of ||u||_F^2 goes to u2_partials.
+// NSG = 128-sample groups (S <= 128 NSG); a workgroup has 4 NSG waves.  Small chunks keep the register count low
+// (n_u = 12: ~130): what hides the chains and the load latency is the number of resident workgroups.
+constexpr int kInnerBuMaxSteps = 1024;
+
+template <int NU, int NSG>
+__global__ __launch_bounds__(256 * NSG) void k_inner_bu(const double* __restrict__ cm, const double* __restrict__ beta_g,
+                                                        double* __restrict__ u, double* __restrict__ u_prev,
+                                                        const SolverState* __restrict__ state,
+                                                        const double* __restrict__ V,
+                                                        const unsigned short* __restrict__ D16, int SD, int64_t N, int S,
+                                                        int n_iter2, int mode, double* __restrict__ slab,
+                                                        double* __restrict__ u2_partials) {
+    static_assert(NU >= 1 && NU <= 16 && (NSG == 1 || NSG == 2), "one row per DPP row; S <= 256");
+    constexpr int NP = NU * (NU + 1) / 2, NV = NU + NP;
+    constexpr int NWV = 4 * NSG, kChunk = 16 * NSG, kRows = 4 * NSG;
+    constexpr int US = NU + (NU & 1);  // row stride of the LDS tile of finished rows (even: 16-byte reads of pairs)
+    typedef double v2d_t __attribute__((ext_vector_type(2)));
+    extern __shared__ double lds_ib[];
+    double* __restrict__ beta_tab = lds_ib;
+    double* __restrict__ u_s = lds_ib + ((n_iter2 + 1) & ~1);  // [2][kChunk][US]
+    double* __restrict__ red = u_s + 2 * kChunk * US;          // [NSG][NU][2][64], then [NWV] for ||u||^2
+    if (state->done) return;
+    for (int t = threadIdx.x; t < n_iter2; t += 256 * NSG) beta_tab[t] = beta_g[t];
+    const double inv_lw = 1.0 / state->l_w;  // as in k_u_phase_mfma
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int j = lane & 15, sub = lane >> 4, jc = j < NU ? j : 0;
+    const int sg = wave >> 2, wr = wave & 3;
+    const int s = sg * 128 + 2 * lane;
+    const bool active = s < S;  // (S even: both samples or none)
+    const int sc = active ? s : S - 2;
+    double acc[NU][2];
+#pragma unroll
+    for (int l = 0; l < NU; ++l) acc[l][0] = acc[l][1] = 0.0;
+    double u2 = 0.0;
+    __syncthreads();
+
+    const int64_t nchunks = (N + kChunk - 1) / kChunk;
+    int it = 0;
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x, ++it) {
+        const int64_t row0 = chunk * kChunk;
+        // ---- loads: the chain's operands first (waited for first), then the b_u stream's pieces
+        const int64_t row = row0 + wave * 4 + sub;
+        const bool ok = j < NU && row < N;
+        const int64_t rowc = row < N ? row : 0;
+        const double* __restrict__ mine = cm + rowc * NV;
+        const double cj = mine[jc];
+        double Mneg[NU];
+#pragma unroll
+        for (int l = 0; l < NU; ++l) Mneg[l] = -mine[NU + (l <= jc ? tri(l, jc) : tri(jc, l))];
+        const int64_t gi = rowc * NU + jc;
+        double uu = ok ? u[gi] : 0.0, up = ok ? u_prev[gi] : 0.0;
+        v2d_t vv[kRows];
+        unsigned int dd[kRows];
+#pragma unroll
+        for (int x = 0; x < kRows; ++x) {
+            const int64_t r = row0 + kRows * wr + x;
+            const int64_t rc = r < N ? r : N - 1;
+            dd[x] = r < N ? *reinterpret_cast<const unsigned int*>(D16 + rc * SD + sc) : 0u;
+            vv[x] = *reinterpret_cast<const v2d_t*>(V + rc * S + sc);
+        }
+        // ---- the chunk's inner iterations (same arithmetic as k_u_inner_rows16)
+        for (int t2 = 0; t2 < n_iter2; ++t2) {
+            const double beta = beta_tab[t2];
+            const double ut = uu + beta * (uu - up);
+            const double base = mode == 1 ? uu : ut;  // deconvolution.py:163 vs :88
+            up = uu;
+            double g = cj;
+            grad_row16<NU>(g, base, Mneg);
+            uu = fmin(fmax(fma(g, inv_lw, ut), 0.0), 1.0);
+        }
+        double* __restrict__ tile = u_s + (it & 1) * kChunk * US;
+        if (ok) {
+            u[gi] = uu;
+            u_prev[gi] = up;
+            u2 = fma(uu, uu, u2);
+        }
+        if (j < NU) tile[(wave * 4 + sub) * US + j] = ok ? uu : 0.0;
+        __syncthreads();  // the tile is complete (and, double buffered, not rewritten before every wave has read it)
+        // ---- b_u of this wave's rows
+#pragma unroll
+        for (int x = 0; x < kRows; ++x) {
+            const double t0 = (double)(dd[x] & 0xFFFFu) * vv[x].x;
+            const double t1 = (double)(dd[x] >> 16) * vv[x].y;
+            const double* __restrict__ ur = tile + (kRows * wr + x) * US;
+#pragma unroll
+            for (int l = 0; l + 1 < NU; l += 2) {
+                const v2d_t u01 = *reinterpret_cast<const v2d_t*>(ur + l);
+                acc[l][0] = fma(t0, u01.x, acc[l][0]);
+                acc[l][1] = fma(t1, u01.x, acc[l][1]);
+                acc[l + 1][0] = fma(t0, u01.y, acc[l + 1][0]);
+                acc[l + 1][1] = fma(t1, u01.y, acc[l + 1][1]);
+            }
+            if constexpr (NU & 1) {
+                const double ul = ur[NU - 1];
+                acc[NU - 1][0] = fma(t0, ul, acc[NU - 1][0]);
+                acc[NU - 1][1] = fma(t1, ul, acc[NU - 1][1]);
+            }
+        }
+    }
+    // ---- the workgroup's slab: waves of a sample group summed in wave order
+    double* __restrict__ part = red + (size_t)sg * NU * 2 * 64;
+    for (int r = 1; r < 4; ++r) {
+        __syncthreads();
+        if (wr == r) {
+#pragma unroll
+            for (int l = 0; l < NU; ++l) {
+                part[(l * 2 + 0) * 64 + lane] = acc[l][0];
+                part[(l * 2 + 1) * 64 + lane] = acc[l][1];
+            }
+        }
+        __syncthreads();
+        if (wr == 0) {
+#pragma unroll
+            for (int l = 0; l < NU; ++l) {
+                acc[l][0] += part[(l * 2 + 0) * 64 + lane];
+                acc[l][1] += part[(l * 2 + 1) * 64 + lane];
+            }
+        }
+    }
+    if (wr == 0 && active) {
+#pragma unroll
+        for (int l = 0; l < NU; ++l) {
+            double* __restrict__ out = slab + ((int64_t)blockIdx.x * NU + l) * S + s;
+            out[0] = acc[l][0];
+            out[1] = acc[l][1];
+        }
+    }
+    __syncthreads();
+    u2 = wave_sum(u2);
+    double* __restrict__ u2w = red;  // (the b_u sums have been consumed)
+    if (lane == 0) u2w[wave] = u2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) tot += u2w[w];
+        u2_partials[blockIdx.x] = tot;
+    }
+}
+
+bool u_inner_bu_supported(const double* V, int S, int SD, int n_u, int n_iter2) {
+    return n_u >= 5 && n_u <= 16 && S >= 2 && (S & 1) == 0 && S <= 256 && (SD & 1) == 0 && n_iter2 <= kInnerBuMaxSteps &&
+           (reinterpret_cast<uintptr_t>(V) & 15) == 0;
+}
+
+int u_inner_bu_grid(int64_t N, int S) {
+    const int64_t nchunks = S <= 128 ? (N + 15) / 16 : (N + 31) / 32;
+    const int64_t cap = S <= 128 ? 2048 : 1024;  // up to eight (four) workgroups of four (eight) waves per CU
+    return (int)(nchunks < cap ? (nchunks < 1 ? 1 : nchunks) : cap);
+}
+
+// cm + beta as launch_u_inner; slab: u_inner_bu_grid(N, S) x n_u x S doubles; u2_partials: one double per workgroup
+static hipError_t launch_u_inner_bu(const double* cm, double* beta, double* u, double* u_prev, const SolverState* state,
+                                    const double* V, const unsigned short* D16, int SD, int64_t N, int S, int n_u,
+                                    int n_iter2, int mode, double* slab, double* u2_partials, int* grid_out,
+                                    hipStream_t st) {
+    if (!u_inner_bu_supported(V, S, SD, n_u, n_iter2)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_beta_table, dim3(1), dim3(1), 0, st, state, n_iter2, beta);
+    const int grid = u_inner_bu_grid(N, S);
+    *grid_out = grid;
+    const int nsg = S <= 128 ? 1 : 2;
+    const int us = n_u + (n_u & 1);
+    const size_t lds = ((size_t)((n_iter2 + 1) & ~1) + (size_t)2 * 16 * nsg * us + (size_t)nsg * n_u * 2 * 64) * sizeof(double);
+#define DMF_CASE(NU_)                                                                                                  \
+    case NU_:                                                                                                          \
+        if (nsg == 1)                                                                                                  \
+            hipLaunchKernelGGL((k_inner_bu<NU_, 1>), dim3((unsigned)grid), dim3(256), lds, st, cm, beta, u, u_prev, state, V, \
+                               D16, SD, N, S, n_iter2, mode, slab, u2_partials);                                       \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_inner_bu<NU_, 2>), dim3((unsigned)grid), dim3(512), lds, st, cm, beta, u, u_prev, state, V, \
+                               D16, SD, N, S, n_iter2, mode, slab, u2_partials);                                       \
+        break;
+    switch (n_u) {
+        DMF_CASE(5) DMF_CASE(6) DMF_CASE(7) DMF_CASE(8) DMF_CASE(9) DMF_CASE(10) DMF_CASE(11) DMF_CASE(12) DMF_CASE(13)
+        DMF_CASE(14) DMF_CASE(15) DMF_CASE(16)
+        default: return hipErrorInvalidValue;
+    }
+#undef DMF_CASE
+    return hipGetLastError();
+}
+
 int64_t u_phase_split_cm_doubles(int64_t N, int n_u) { return N * (n_u + (int64_t)n_u * (n_u + 1) / 2); }
 
 // the inner iterations from cm (N x (n_u + NP) doubles); beta: n_iter2 doubles of device scratch
@@ -554,6 +752,18 @@ hipError_t launch_u_phase_split_i8(const double* V, const unsigned short* D16, i
     hipError_t e = launch_cm_i8(V, D16, SD, ND, Rt, alpha, state, N, S, n_c, n_u, cm, st);
     if (e != hipSuccess) return e;
     return launch_u_inner(cm, beta, u, u_prev, state, N, n_u, n_iter2, mode, st);
+}
+
+// producer of dmf_kernels_cm_i8.hip, then the inner iterations fused with the b_u stream (k_inner_bu): the whole u phase
+// plus b_u and ||u||^2 of the integer Gram route in two launches (+ the momentum table)
+hipError_t launch_u_phase_split_i8_bu(const double* V, const unsigned short* D16, int SD, int ND, const double* Rt,
+                                      const double* alpha, double* u, double* u_prev, const SolverState* state, int64_t N,
+                                      int S, int n_c, int n_u, int n_iter2, int mode, double* cm, double* beta,
+                                      double* slab, double* u2_partials, int* grid_out, hipStream_t st) {
+    if (cm == nullptr || beta == nullptr || slab == nullptr || u2_partials == nullptr) return hipErrorInvalidValue;
+    hipError_t e = launch_cm_i8(V, D16, SD, ND, Rt, alpha, state, N, S, n_c, n_u, cm, st);
+    if (e != hipSuccess) return e;
+    return launch_u_inner_bu(cm, beta, u, u_prev, state, V, D16, SD, N, S, n_u, n_iter2, mode, slab, u2_partials, grid_out, st);
 }
 
 }  // namespace dmf

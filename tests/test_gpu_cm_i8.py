@@ -42,7 +42,36 @@ def test_cm_i8_shapes_against_oracle(ctx, N, S, n_c, n_u, T1, depth, why):
     mode = L.DMF_MODE_PARTIAL if n_c else L.DMF_MODE_UNSUPERVISED
     nd = 1 if D.max() <= 127 else 2
     u, alpha, cost, direct, _ = _solve_at_level(ctx, 0, V, D, Rt if n_c else None, u0, a0, mode, T1,
-                                                [f"rowpass=k_cm_i8<nd={nd}>+k_u_inner_rows"])
+                                                [f"rowpass=k_cm_i8<nd={nd}>+"])
+    assert rel_err(alpha, wa) < TIGHT and np.abs(alpha - wa).max() < TIGHT, why
+    assert np.abs(u - wu).max() < TIGHT, why
+    want = osol.weighted_cost(V, np.c_[Rt, wu] if n_c else wu, wa, D)
+    assert cost == pytest.approx(want, rel=1e-9) and direct == pytest.approx(want, rel=1e-11)
+
+
+# the integer Gram route behind it for many features: more than 64 per launch -> several launches over the 8-bit planes;
+# x image (padded known types + unknowns) up to 32 doubles per row; k_bu_cols2 up to 16 unknowns
+WIDE_GRAM_CASES = [
+    (1500, 128, 0, 12, 3, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "78 features: two launches, no known types"),
+    (1000, 128, 0, 16, 2, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "136 features: three launches, 16 unknowns"),
+    (1200, 128, 12, 12, 2, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "222 features, x image of 24 doubles"),
+    (800, 128, 16, 8, 2, 3000, ["k_cm_i8<nd=2>+k_inner_bu", "gram=k_gram_i8<nd=2>"], "164 features, two count digits, ring of six"),
+    (2500, 200, 5, 9, 2, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "two 128-sample groups (eight-wave k_inner_bu), ragged second group, odd n_u"),
+    (1100, 256, 0, 8, 2, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "two full 128-sample groups, 1100 rows = 34 chunks + 12 rows"),
+    (70, 4, 9, 5, 3, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "S = 4: two lanes of the b_u stream active; 70 rows = 2 chunks + 6 rows"),
+    (600, 130, 3, 13, 2, 40, ["gram=k_bu_cols+k_gram_i8<nd=1>"], "S = 2 mod 4: the producer does not take it, the Gram route (k_bu_cols2<13>) does"),
+    (700, 64, 15, 16, 2, 40, ["k_cm_i8<nd=1>+k_u_inner_rows"], "376 features: beyond the integer Gram's cap, k_gram_mfma behind k_cm_i8; K = 31"),
+]
+
+
+@pytest.mark.parametrize("N,S,n_c,n_u,T1,depth,expect,why", WIDE_GRAM_CASES)
+def test_wide_gram_routes_against_oracle(ctx, N, S, n_c, n_u, T1, depth, expect, why):
+    from demethify_amd import _lib as L
+
+    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=29, depth=depth)
+    u0, a0, wu, wa = _oracle(V, D, Rt, n_c, n_u, T1, seed=4)
+    mode = L.DMF_MODE_PARTIAL if n_c else L.DMF_MODE_UNSUPERVISED
+    u, alpha, cost, direct, _ = _solve_at_level(ctx, 0, V, D, Rt if n_c else None, u0, a0, mode, T1, expect)
     assert rel_err(alpha, wa) < TIGHT and np.abs(alpha - wa).max() < TIGHT, why
     assert np.abs(u - wu).max() < TIGHT, why
     want = osol.weighted_cost(V, np.c_[Rt, wu] if n_c else wu, wa, D)
