@@ -391,6 +391,10 @@ hipError_t enqueue_cost(dmf_context* ctx, const dmf_problem* p, const double* u,
         dmf::cost_cols_supported((int)p->S, (int)p->n_c, n_u))
         return dmf::launch_cost_cols(p->V, p->D, p->D16, p->SD, p->Rtp, u, alpha, p->N, (int)p->S, (int)p->n_c, n_u,
                                      scratch, out, ctx->stream);
+    if (ctx->generic_level == 0 && rtp_ok &&
+        dmf::cost_cols2_wide_supported(p->V, p->D16, (int)p->S, p->SD, (int)p->n_c, n_u))
+        return dmf::launch_cost_cols2_wide(p->V, p->D16, p->SD, p->Rtp, u, alpha, p->N, (int)p->S, (int)p->n_c, n_u, scratch,
+                                           out, ctx->stream);
     return dmf::launch_cost(p->V, p->D, p->Rt, u, alpha, p->N, (int)p->S, (int)p->n_c, n_u, scratch, out, ctx->stream);
 }
 
@@ -969,6 +973,12 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
                 (reinterpret_cast<uintptr_t>(p->V) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0 &&
                 dmf::rowpass_v2_supported((int)S, (int)n_c, (int)n_u, 20) &&
                 dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
+    // Wide row groups (n_u 5..16) on u16 counts: the split u phase with the integer-matrix-core producer.  Measured at
+    // 5e5 x 128 against what ran before: see DESIGN.md section 5.  DMF_CM_I8_MIN_NU moves the lower end (experiments).
+    static const int cm_min_nu = [] { const char* v = getenv("DMF_CM_I8_MIN_NU"); return v != nullptr && atoi(v) > 0 ? atoi(v) : 5; }();
+    s->use_cm_i8 = ctx->generic_level == 0 && !s->use_v2 && p->ND > 0 && p->D16 != nullptr && n_u >= cm_min_nu && n_u <= 16 &&
+                   (n_c == 0 || (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 7) == 0)) &&
+                   dmf::cm_i8_supported(p->V, (int)S, (int)n_c, (int)n_u, p->ND, p->SD);
     // shapes the second-generation row pass does not take (n_u 5..20, long inner loops): the u phase stays a kernel of its
     // own, the Gram pass becomes the integer GEMM + the b_u stream kernel (V f64 + u16 counts instead of V and D f64
     // and n_u (n_u + 3) / 2 + n_c n_u FP64 FMAs per element)
@@ -982,18 +992,17 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     // accumulators on.  DMF_GRAM_I8_MIN moves the threshold (experiments).
     static const int i8_min_features = [] { const char* v = getenv("DMF_GRAM_I8_MIN"); return v != nullptr ? atoi(v) : 48; }();
     const int fp64_acc = (int)((n_c + 3) / 4 * 4 * n_u + n_u * (n_u + 1) / 2 + n_u);
+    static const int i8_min_nc0 = [] { const char* v = getenv("DMF_GRAM_I8_MIN_NC0"); return v != nullptr ? atoi(v) : 33; }();
     // (without known types: from 8 unknowns -- 36 features -- on.  At 5e5 x 128 with k_bu_cols2 up to 16 unknowns:
     // 0+8 0.24 -> 0.20 ms, 0+12 0.36 -> 0.29, 0+16 0.67 (k_gram_mfma) -> 0.36; below 8 k_gram_u is cheaper.)
+    // Behind k_cm_i8 the b_u stream rides along with the inner iterations (k_inner_bu) and the integer route is what is
+    // left of the Gram pass: it then wins at every width (0+5 / 0+6 / 0+7 at 5e5 x 128: 0.58 / 0.55 / 0.59 -> 0.51 / 0.49 /
+    // 0.53 ms per iteration against k_gram_u).
+    const bool fused_bu = s->use_cm_i8 && dmf::u_inner_bu_supported(p->V, (int)S, p->SD, (int)n_u, 20);
     const bool known_ok = n_c > 0 ? (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0) : true;
     s->use_gram_i8 = ctx->generic_level == 0 && p->ND > 0 && p->D16 != nullptr && known_ok &&
-                     (n_c > 0 ? fp64_acc >= i8_min_features : n_c * n_u + n_u * (n_u + 1) / 2 >= 33) && n_u <= 20 &&
+                     (fused_bu || (n_c > 0 ? fp64_acc >= i8_min_features : n_u * (n_u + 1) / 2 >= i8_min_nc0)) && n_u <= 20 &&
                      dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
-    // Wide row groups (n_u 5..16) on u16 counts: the split u phase with the integer-matrix-core producer.  Measured at
-    // 5e5 x 128 against what ran before: see DESIGN.md section 5.  DMF_CM_I8_MIN_NU moves the lower end (experiments).
-    static const int cm_min_nu = [] { const char* v = getenv("DMF_CM_I8_MIN_NU"); return v != nullptr && atoi(v) > 0 ? atoi(v) : 5; }();
-    s->use_cm_i8 = ctx->generic_level == 0 && !s->use_v2 && p->ND > 0 && p->D16 != nullptr && n_u >= cm_min_nu && n_u <= 16 &&
-                   (n_c == 0 || (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 7) == 0)) &&
-                   dmf::cm_i8_supported(p->V, (int)S, (int)n_c, (int)n_u, p->ND, p->SD);
     if (s->use_v2 || s->use_cm_i8) {
         // the row pass writes alpha_j alpha_l in fixed point on [0, 1]: true of every iterate (columns on the simplex),
         // checked for the caller's starting point

@@ -76,6 +76,10 @@ hipError_t launch_cost(const double* V, const double* D, const double* Rt, const
 // the same cost for n_c <= 16, n_u <= 4 with the lane's alpha column in registers: Rtp = padded R_trunc copy,
 // D16 (u16 counts, row stride SD) is read instead of D when it is not null
 bool cost_cols_supported(int S, int n_c, int n_u);
+bool cost_cols2_wide_supported(const double* V, const unsigned short* D16, int S, int SD, int n_c, int n_u);
+hipError_t launch_cost_cols2_wide(const double* V, const unsigned short* D16, int SD, const double* Rtp, const double* u,
+                                  const double* alpha, int64_t N, int S, int n_c, int n_u, double* scratch, double* out,
+                                  hipStream_t st);
 int vdv_cols_grid(int64_t N);
 hipError_t launch_vdv_cols(const double* V, const double* D, const unsigned short* D16, int SD, int64_t N, int S, double* slab,
                            double* out, hipStream_t st);

@@ -449,6 +449,53 @@ hipError_t launch_cost_cols(const double* V, const double* D, const unsigned sho
     }
 }
 
+// Wide row groups (5..16 unknowns): the two-samples-per-lane form only (u16 counts, S even and >= 128, 16-B aligned V);
+// other shapes of that width stay on the generic k_cost.
+bool cost_cols2_wide_supported(const double* V, const unsigned short* D16, int S, int SD, int n_c, int n_u) {
+    return D16 != nullptr && n_c <= 16 && n_u >= 5 && n_u <= 16 && S % 2 == 0 && S >= 128 && SD % 2 == 0 &&
+           (reinterpret_cast<uintptr_t>(V) & 15) == 0;
+}
+
+template <int NKC, int NU>
+static hipError_t launch_cost_cols2_wide_t(const double* V, const unsigned short* D16, int SD, const double* Rtp,
+                                           const double* u, const double* alpha, int64_t N, int S, int n_c, double* scratch,
+                                           double* out, hipStream_t st) {
+    const int ny2 = (S + 127) / 128;
+    const int64_t want = (N + 4 * 8 - 1) / (4 * 8);
+    int nbx = (int)(want < 1 ? 1 : want);
+    if (nbx > 1024 / ny2) nbx = 1024 / ny2;  // scratch: 1024 partials
+    hipLaunchKernelGGL((k_cost_cols2<NKC, NU>), dim3(nbx, ny2), dim3(256), 0, st, V, D16, SD, Rtp, u, alpha, N, S, n_c, scratch);
+    hipLaunchKernelGGL(k_reduce_final<1>, dim3(1), dim3(256), 0, st, scratch, nbx * ny2, out, (const int*)nullptr);
+    return hipGetLastError();
+}
+
+template <int NKC>
+static hipError_t launch_cost_cols2_wide_nkc(int n_u, const double* V, const unsigned short* D16, int SD, const double* Rtp,
+                                             const double* u, const double* alpha, int64_t N, int S, int n_c,
+                                             double* scratch, double* out, hipStream_t st) {
+    switch (n_u) {
+#define DMF_CASE(NU_) \
+    case NU_: return launch_cost_cols2_wide_t<NKC, NU_>(V, D16, SD, Rtp, u, alpha, N, S, n_c, scratch, out, st);
+        DMF_CASE(5) DMF_CASE(6) DMF_CASE(7) DMF_CASE(8) DMF_CASE(9) DMF_CASE(10) DMF_CASE(11) DMF_CASE(12) DMF_CASE(13)
+        DMF_CASE(14) DMF_CASE(15) DMF_CASE(16)
+#undef DMF_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_cost_cols2_wide(const double* V, const unsigned short* D16, int SD, const double* Rtp, const double* u,
+                                  const double* alpha, int64_t N, int S, int n_c, int n_u, double* scratch, double* out,
+                                  hipStream_t st) {
+    if (!cost_cols2_wide_supported(V, D16, S, SD, n_c, n_u)) return hipErrorInvalidValue;
+    switch ((n_c + 3) / 4) {
+#define DMF_NKC(X) \
+    case X: return launch_cost_cols2_wide_nkc<X>(n_u, V, D16, SD, Rtp, u, alpha, N, S, n_c, scratch, out, st);
+        DMF_NKC(0) DMF_NKC(1) DMF_NKC(2) DMF_NKC(3) DMF_NKC(4)
+#undef DMF_NKC
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_cost(const double* V, const double* D, const double* Rt, const double* u,
                        const double* alpha, int64_t N, int S, int n_c, int n_u,
                        double* scratch, double* out, hipStream_t st) {

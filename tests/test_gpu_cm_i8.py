@@ -59,6 +59,8 @@ WIDE_GRAM_CASES = [
     (2500, 200, 5, 9, 2, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "two 128-sample groups (eight-wave k_inner_bu), ragged second group, odd n_u"),
     (1100, 256, 0, 8, 2, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "two full 128-sample groups, 1100 rows = 34 chunks + 12 rows"),
     (70, 4, 9, 5, 3, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "S = 4: two lanes of the b_u stream active; 70 rows = 2 chunks + 6 rows"),
+    (2000, 128, 0, 6, 3, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "21 features only: behind the fused b_u stream the integer route runs at every width"),
+    (1200, 64, 1, 5, 3, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "one known type, five unknowns (20 features)"),
     (600, 130, 3, 13, 2, 40, ["gram=k_bu_cols+k_gram_i8<nd=1>"], "S = 2 mod 4: the producer does not take it, the Gram route (k_bu_cols2<13>) does"),
     (700, 64, 15, 16, 2, 40, ["k_cm_i8<nd=1>+k_u_inner_rows"], "376 features: beyond the integer Gram's cap, k_gram_mfma behind k_cm_i8; K = 31"),
 ]

@@ -14,6 +14,8 @@ dev = torch.device("cuda", 0)
 ctx = Context(0)
 cases = [(500_000, 128, 0, n) for n in (5, 6, 7, 8, 9, 10, 12, 14, 16)] + [(500_000, 128, 12, n) for n in (5, 6, 8, 12)] + [(500_000, 128, 4, 12), (500_000, 128, 8, 8), (500_000, 128, 16, 16)] + \
         [(250_000, 256, 0, 8), (250_000, 256, 12, 6), (250_000, 64, 4, 8)]
+if len(sys.argv) > 1:
+    cases = [(500_000, 128, 0, n) for n in (5, 6, 7)]
 for N, S, n_c, n_u in cases:
     V, D, Rt = make_inputs_on_device(torch, dev, N, S, max(n_c, 1), n_u, seed=0)
     p = Problem(ctx, V, D, Rt if n_c else None)
