@@ -116,3 +116,27 @@ def test_update_u_known_answer_on_cm_i8(ctx, n_c, n_u):
         got = p.update_u(u, u_prev, alpha, 20, a1, l_w_prev, l_w)
     assert np.abs(got[0] - want[0]).max() < 1e-11 and np.abs(got[1] - want[1]).max() < 1e-11
     assert got[2] == pytest.approx(want[2], rel=1e-15) and got[3] == want[3]
+
+
+def test_purity_constrained_solver_on_wide_row_groups(ctx):
+    """mdwbssmf_deconv_p with six unknowns: 70 inner steps through k_cm_i8 + k_inner_bu, Frank-Wolfe alpha phase."""
+    from demethify_amd import deconvolution as dd
+
+    V, D, Rt = osol.synthetic_problem(900, 128, 3, 6, seed=13, depth=25)
+    purity = np.linspace(0.2, 0.9, 128)
+    u0, R, a0 = osol.init_partial_purity("uniform_", V, D, Rt, 6, purity, seed=5)
+    wu, wa = osol.solve_partial_purity(u0.copy(), R, a0.copy(), V, D, Rt, 6, purity, 3, 70, 0.0)
+    gu, ga = dd.mdwbssmf_deconv_p(u0.copy(), R.copy(), a0.copy(), V, D, Rt, 6, purity, n_iter1=3, n_iter2=70, tol=0.0)
+    assert rel_err(ga, wa) < TIGHT and np.abs(gu - wu).max() < TIGHT
+    assert np.allclose(ga[:3].sum(axis=0), purity, atol=1e-12) and np.allclose(ga[3:].sum(axis=0), 1 - purity, atol=1e-12)
+
+
+def test_more_inner_steps_than_the_fused_kernel_holds(ctx):
+    """1100 inner steps: beyond k_inner_bu's momentum table -> k_cm_i8 + k_u_inner_rows16 (chunked table) + k_bu_cols."""
+    from demethify_amd import deconvolution as dd
+
+    V, D, Rt = osol.synthetic_problem(300, 64, 2, 5, seed=3, depth=25)
+    u0, R, a0 = osol.init_partial("uniform_", V, D, Rt, 5, seed=2)
+    wu, wa = osol.solve_partial(u0.copy(), R, a0.copy(), V, D, Rt, 5, 2, 1100, 0.0, project=osol.simplex_project_columns_fast)
+    gu, ga = dd.mdwbssmf_deconv(u0, R, a0, V, D, Rt, 5, n_iter1=2, n_iter2=1100, tol=0.0)
+    assert rel_err(ga, wa) < TIGHT and np.abs(gu - wu).max() < TIGHT
