@@ -206,9 +206,10 @@ def main():
         kernels = s.describe(T2)
         s.step(args.warmup, T2, 0.0)
         s.direct_cost()
-    if world > 1:
-        shard.allreduce_min_vector({rank: 0.0}, world)
-        shard.broadcast_arrays((np.zeros(8),), 0)
+        if world > 1:
+            # the job's two exchanges at their real sizes: RCCL connects its rings on the first large message
+            shard.allreduce_min_vector({rank: 0.0}, world)
+            shard.broadcast_winner(s if rank == 0 else None, (N, n_u), (K, S), 0)
     ctx.synchronize()
     # HIP events around the two families that stream V / D (the roofline kernel is one of them), on the stream
     # the kernels are launched on; the KB-sized alpha phase is timed after the job
