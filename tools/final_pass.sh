@@ -15,3 +15,6 @@ timeout -k 10 200 python tools/restart_overheads.py 2>&1 | grep -v amdgpu.ids > 
 du -sh gpurun_out/final
 DMF_BENCH_DEPTH=120 python bench.py --no-cpu-baseline --restarts 8 > gpurun_out/final/deep_coverage_bench_line.json 2> gpurun_out/final/deep.err
 timeout -k 10 400 python tools/ic_sweep_bench.py 50 2>&1 | grep -v amdgpu.ids > gpurun_out/final/ic_sweep.txt
+timeout -k 10 300 python tools/wide_nu_sweep.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/wide_row_groups.txt
+bash tools/pmc_shape.sh final/pmc_0_8 500000 128 0 8 6 > /dev/null && python3 tools/pmc_summary.py gpurun_out/final/pmc_0_8 > gpurun_out/final/wide_pmc_0_8.txt
+bash tools/pmc_shape.sh final/pmc_0_12 500000 128 0 12 6 > /dev/null && python3 tools/pmc_summary.py gpurun_out/final/pmc_0_12 > gpurun_out/final/wide_pmc_0_12.txt
