@@ -16,3 +16,12 @@ def test_random_shapes_against_oracle():
                           capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0 and "MISMATCH" not in proc.stdout, (proc.stdout[-3000:], proc.stderr[-2000:])
     assert "90 cases" in proc.stdout
+
+
+def test_random_wide_row_groups_against_oracle():
+    """The same with a bias towards 5..16 unknown types on S % 4 == 0 (k_cm_i8 + k_inner_bu and the many-feature integer
+    Gram behind them)."""
+    proc = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz_parity.py"), "70", "5", "wide"], cwd=ROOT,
+                          capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0 and "MISMATCH" not in proc.stdout, (proc.stdout[-3000:], proc.stderr[-2000:])
+    assert "70 cases" in proc.stdout and "k_cm_i8" in proc.stdout
