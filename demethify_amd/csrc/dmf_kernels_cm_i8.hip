@@ -130,13 +130,14 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
         const int64_t row = b * 32 + 16 * h + m16;
         return row < N ? row : N - 1;
     };
-    // strip t of column group cg: a lane's four samples start at c = 64 cg + 16 t + 4 q; S % 4 == 0, so they are all in
-    // range or all out -- out-of-range samples read V at column 0 (finite) against zero-padded counts
+    // strip t of column group cg: a lane's four samples start at c = 64 cg + 16 t + 4 q; S is even, so they go in or out
+    // of range in pairs -- out-of-range samples read V at an in-range column (finite) against zero-padded counts
     auto load_strip = [&](int64_t rowc, int cg, int t, v4d& e, unsigned long long& d) {
         const int c = 64 * cg + 16 * t + 4 * q;
-        const double* __restrict__ vp = V + rowc * S + (c < S ? c : 0);
+        const int cb = c < S ? c : 0;
+        const double* __restrict__ vp = V + rowc * S + cb;
         const v2d v01 = *reinterpret_cast<const v2d*>(vp);
-        const v2d v23 = *reinterpret_cast<const v2d*>(vp + 2);
+        const v2d v23 = *reinterpret_cast<const v2d*>(vp + (cb + 2 < S ? 2 : 0));
         e = v4d{v01.x, v01.y, v23.x, v23.y};
         d = *reinterpret_cast<const unsigned long long*>(D16 + rowc * SD + c);
     };
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
 
 bool cm_i8_supported(const double* V, int S, int n_c, int n_u, int ND, int SD) {
     if (n_u < 1 || n_u > 16 || n_c < 0 || n_c > 16) return false;
-    if (S < 4 || (S & 3) != 0 || S > 256 || (SD & 3) != 0 || SD < (S + 63) / 64 * 64) return false;
+    if (S < 2 || (S & 1) != 0 || S > 256 || (SD & 3) != 0 || SD < (S + 63) / 64 * 64) return false;
     if (ND != 1 && ND != 2) return false;
     if ((reinterpret_cast<uintptr_t>(V) & 15) != 0) return false;
     return cm_layout(S, n_c, n_u).bytes <= 160 * 1024;

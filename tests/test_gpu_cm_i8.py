@@ -61,7 +61,9 @@ WIDE_GRAM_CASES = [
     (70, 4, 9, 5, 3, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "S = 4: two lanes of the b_u stream active; 70 rows = 2 chunks + 6 rows"),
     (2000, 128, 0, 6, 3, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "21 features only: behind the fused b_u stream the integer route runs at every width"),
     (1200, 64, 1, 5, 3, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "one known type, five unknowns (20 features)"),
-    (600, 130, 3, 13, 2, 40, ["gram=k_bu_cols+k_gram_i8<nd=1>"], "S = 2 mod 4: the producer does not take it, the Gram route (k_bu_cols2<13>) does"),
+    (600, 130, 3, 13, 2, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "S = 2 mod 4: the last lane of a row holds one pair in range and one out"),
+    (300, 2, 2, 6, 3, 40, ["k_cm_i8<nd=1>+k_inner_bu"], "two samples"),
+    (450, 6, 0, 9, 3, 900, ["k_cm_i8<nd=2>+k_inner_bu"], "six samples, two count digit planes"),
     (700, 64, 15, 16, 2, 40, ["k_cm_i8<nd=1>+k_u_inner_rows"], "376 features: beyond the integer Gram's cap, k_gram_mfma behind k_cm_i8; K = 31"),
 ]
 
