@@ -53,8 +53,9 @@ __host__ __device__ inline CmLayout cm_layout(int S, int n_c, int n_u) {
 }
 
 // NKC = ceil(n_c / 4); ND = count digit planes (1: every count <= 127, 2: <= 32639); NCGX >= number of 64-sample
-// column groups (the per-group loops are unrolled NCGX times behind wave-uniform guards).
-template <int NKC, int ND, int NCGX>
+// column groups (the per-group loops are unrolled NCGX times behind wave-uniform guards); S4: S % 4 == 0 (the plain
+// strip loads; any other S >= 2 takes the form with per-pair offsets).
+template <int NKC, int ND, int NCGX, bool S4>
 __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, const unsigned short* __restrict__ D16, int SD,
                                                const double* __restrict__ Rtp, const double* __restrict__ alpha,
                                                const SolverState* __restrict__ state, int64_t N, int S, int n_c, int n_u,
@@ -130,16 +131,34 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
         const int64_t row = b * 32 + 16 * h + m16;
         return row < N ? row : N - 1;
     };
-    // strip t of column group cg: a lane's four samples start at c = 64 cg + 16 t + 4 q; S is even, so they go in or out
-    // of range in pairs -- out-of-range samples read V at an in-range column (finite) against zero-padded counts
+    // strip t of column group cg: a lane's four samples start at c = 64 cg + 16 t + 4 q.  Samples at or beyond S meet
+    // zero-padded counts, so their V only has to be finite: a group out of range reads the row's first group, and a pair
+    // with one sample in range is fetched one element lower (never past the end of the row: the last row of V ends
+    // the array).  With odd S rows start 8 bytes off a 16-byte boundary every other time; 16-byte global loads take that
+    // (tools/align_probe.hip), the type says so.
+    typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
     auto load_strip = [&](int64_t rowc, int cg, int t, v4d& e, unsigned long long& d) {
-        const int c = 64 * cg + 16 * t + 4 * q;
-        const int cb = c < S ? c : 0;
-        const double* __restrict__ vp = V + rowc * S + cb;
-        const v2d v01 = *reinterpret_cast<const v2d*>(vp);
-        const v2d v23 = *reinterpret_cast<const v2d*>(vp + (cb + 2 < S ? 2 : 0));
-        e = v4d{v01.x, v01.y, v23.x, v23.y};
-        d = *reinterpret_cast<const unsigned long long*>(D16 + rowc * SD + c);
+        int c = 64 * cg + 16 * t + 4 * q;
+        if constexpr (S4) {  // S % 4 == 0: a lane's four samples are all in range or all out
+            const double* __restrict__ vp = V + rowc * S + (c < S ? c : 0);
+            const v2d v01 = *reinterpret_cast<const v2d*>(vp);
+            const v2d v23 = *reinterpret_cast<const v2d*>(vp + 2);
+            e = v4d{v01.x, v01.y, v23.x, v23.y};
+        } else {
+            // (recomputed at every use: hoisted out of the row loop, the per-strip lane constants below cost the kernel 30
+            // to 60 registers and, with four column groups, spills)
+            asm volatile("" : "+v"(c));
+            const int left = S - c;
+            const int cb = left > 0 ? c : 0;
+            const int nvb = left > 0 ? left : S;  // samples of the group read that exist (>= 1; S >= 2)
+            const int o01 = nvb >= 2 ? 0 : -1;    // one sample: the pair (cb - 1, cb)
+            const int o23 = nvb >= 4 ? 2 : (nvb == 3 ? 1 : o01);  // three: (cb + 1, cb + 2); fewer: the first pair again
+            const double* __restrict__ vp = V + rowc * S + cb;
+            const v2d_u v01 = *reinterpret_cast<const v2d_u*>(vp + o01);
+            const v2d_u v23 = *reinterpret_cast<const v2d_u*>(vp + o23);
+            e = v4d{nvb >= 2 ? v01.x : v01.y, v01.y, nvb == 3 ? v23.y : v23.x, v23.y};
+        }
+        d = *reinterpret_cast<const unsigned long long*>(D16 + rowc * SD + (64 * cg + 16 * t + 4 * q));
     };
 
     v4d nv[4];
@@ -296,13 +315,13 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
 
 bool cm_i8_supported(const double* V, int S, int n_c, int n_u, int ND, int SD) {
     if (n_u < 1 || n_u > 16 || n_c < 0 || n_c > 16) return false;
-    if (S < 2 || (S & 1) != 0 || S > 256 || (SD & 3) != 0 || SD < (S + 63) / 64 * 64) return false;
+    if (S < 2 || S > 256 || (SD & 3) != 0 || SD < (S + 63) / 64 * 64) return false;
     if (ND != 1 && ND != 2) return false;
-    if ((reinterpret_cast<uintptr_t>(V) & 15) != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(V) & 7) != 0) return false;
     return cm_layout(S, n_c, n_u).bytes <= 160 * 1024;
 }
 
-template <int NKC, int ND, int NCGX>
+template <int NKC, int ND, int NCGX, bool S4>
 static hipError_t launch_cm_t(const double* V, const unsigned short* D16, int SD, const double* Rtp, const double* alpha,
                               const SolverState* state, int64_t N, int S, int n_c, int n_u, double* cm, hipStream_t st) {
     const size_t lds = cm_layout(S, n_c, n_u).bytes;
@@ -310,7 +329,7 @@ static hipError_t launch_cm_t(const double* V, const unsigned short* D16, int SD
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!raised[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_cm_i8<NKC, ND, NCGX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)k_cm_i8<NKC, ND, NCGX, S4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
         if (e != hipSuccess) return e;
         raised[dev] = true;
@@ -322,7 +341,7 @@ static hipError_t launch_cm_t(const double* V, const unsigned short* D16, int SD
     if (const char* v = getenv("DMF_CM_PER_CU")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (experiments)
     const int64_t cap = (int64_t)256 * per_cu;
     const int64_t grid = want < cap ? want : cap;
-    hipLaunchKernelGGL((k_cm_i8<NKC, ND, NCGX>), dim3((unsigned)grid), dim3(kCmWaves * 64), lds, st, V, D16, SD, Rtp, alpha,
+    hipLaunchKernelGGL((k_cm_i8<NKC, ND, NCGX, S4>), dim3((unsigned)grid), dim3(kCmWaves * 64), lds, st, V, D16, SD, Rtp, alpha,
                        state, N, S, n_c, n_u, cm);
     return hipGetLastError();
 }
@@ -332,11 +351,16 @@ static hipError_t launch_cm_nkc(const double* V, const unsigned short* D16, int 
                                 const double* alpha, const SolverState* state, int64_t N, int S, int n_c, int n_u,
                                 double* cm, hipStream_t st) {
     const bool wide = S > 128;
-    if (ND == 1)
-        return wide ? launch_cm_t<NKC, 1, 4>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, st)
-                    : launch_cm_t<NKC, 1, 2>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
-    return wide ? launch_cm_t<NKC, 2, 4>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, st)
-                : launch_cm_t<NKC, 2, 2>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
+#define DMF_CM(ND_, NCGX_)                                                                                               \
+    return (S & 3) == 0 ? launch_cm_t<NKC, ND_, NCGX_, true>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, st)     \
+                        : launch_cm_t<NKC, ND_, NCGX_, false>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, st)
+    if (ND == 1) {
+        if (wide) DMF_CM(1, 4);
+        DMF_CM(1, 2);
+    }
+    if (wide) DMF_CM(2, 4);
+    DMF_CM(2, 2);
+#undef DMF_CM
 }
 
 // cm: N x (n_u + n_u (n_u + 1) / 2) doubles.  Preconditions (cm_i8_supported + the caller): counts integral in

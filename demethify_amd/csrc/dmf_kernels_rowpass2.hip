@@ -24,7 +24,7 @@
 // Rows beyond N in the last block read a clamped V row and zero counts (D16 is zero-padded to a multiple of 16 rows
 // and of 64 columns), so they add nothing; their u is never stored.
 //
-// Preconditions (checked by the launcher / the solver): S even, S <= 256, n_c <= 16, n_u <= 4, counts integral and
+// Preconditions (checked by the launcher / the solver): 2 <= S <= 256 (odd S: see the tile prefetch), n_c <= 16, n_u <= 4, counts integral and
 // <= 32639 (nd = 1: <= 127), alpha within [0, 1] (true of every iterate: columns on the simplex).
 #include "dmf_device.h"
 #include "dmf_internal.h"
@@ -207,7 +207,12 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
     const int ld_row = lane >> 5;
     const int ld_col = (lane & 31) * 2;
     int ld_gcol = wcol0 + ld_col;
-    if (ld_gcol > S - 2) ld_gcol = S - 2;  // ragged last column group: clamped samples meet zero counts
+    // ragged last column group: clamped samples meet zero counts.  Odd S: the row's last sample shares its pair with the
+    // next row's first element (or, on the last row, with a zero from the descriptor's range check) -- a finite value
+    // against a zero count; rows then start 8 bytes off a 16-byte boundary every other time, which 16-byte buffer loads
+    // take (tools/align_probe.hip).
+    const int last_pair = (S - 1) & ~1;
+    if (ld_gcol > last_pair) ld_gcol = last_pair;
     const int d_row = lane >> 3, d_col = (lane & 7) * 8;
     v2d pv[8];
     v4u pd[2];
@@ -512,7 +517,7 @@ size_t rowpass_v2_lds_bytes(int S, int n_u, int n_iter2) {
 }
 
 bool rowpass_v2_supported(int S, int n_c, int n_u, int n_iter2) {
-    if ((S & 1) != 0 || S < 2 || S > 256 || n_c > 16 || n_u < 1 || n_u > 4) return false;
+    if (S < 2 || S > 256 || n_c > 16 || n_u < 1 || n_u > 4) return false;
     return rowpass_v2_lds_bytes(S, n_u, n_iter2) <= 80 * 1024;  // two workgroups per CU within 160 KB
 }
 

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void k_u_inner_rows16(const double* __restrict
 // (n_u = 12: ~130): what hides the chains and the load latency is the number of resident workgroups.
 constexpr int kInnerBuMaxSteps = 1024;
 
-template <int NU, int NSG>
+template <int NU, int NSG, bool ODD>
 __global__ __launch_bounds__(256 * NSG) void k_inner_bu(const double* __restrict__ cm, const double* __restrict__ beta_g,
                                                         double* __restrict__ u, double* __restrict__ u_prev,
                                                         const SolverState* __restrict__ state,
@@ -548,8 +548,14 @@ __global__ __launch_bounds__(256 * NSG) void k_inner_bu(const double* __restrict
     const int j = lane & 15, sub = lane >> 4, jc = j < NU ? j : 0;
     const int sg = wave >> 2, wr = wave & 3;
     const int s = sg * 128 + 2 * lane;
-    const bool active = s < S;  // (S even: both samples or none)
-    const int sc = active ? s : S - 2;
+    const bool active = s < S;
+    // odd S: the row's last sample sits alone in its lane -- its V comes as the upper half of the pair one element lower
+    // (never past the end of the row), its partner's count is zero padding; 16-byte loads from 8-byte-aligned addresses:
+    // tools/align_probe.hip
+    const bool lone = ODD && s == S - 1;
+    const int sc = ODD ? (lone ? S - 2 : (active ? s : 0)) : (active ? s : S - 2);
+    const int sd = ODD ? (active ? s : 0) : sc;
+    typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
     double acc[NU][2];
 #pragma unroll
     for (int l = 0; l < NU; ++l) acc[l][0] = acc[l][1] = 0.0;
@@ -577,8 +583,14 @@ __global__ __launch_bounds__(256 * NSG) void k_inner_bu(const double* __restrict
         for (int x = 0; x < kRows; ++x) {
             const int64_t r = row0 + kRows * wr + x;
             const int64_t rc = r < N ? r : N - 1;
-            dd[x] = r < N ? *reinterpret_cast<const unsigned int*>(D16 + rc * SD + sc) : 0u;
-            vv[x] = *reinterpret_cast<const v2d_t*>(V + rc * S + sc);
+            if constexpr (ODD) {
+                dd[x] = r < N && active ? *reinterpret_cast<const unsigned int*>(D16 + rc * SD + sd) : 0u;
+                const v2d_u vl = *reinterpret_cast<const v2d_u*>(V + rc * S + sc);
+                vv[x] = v2d_t{lone ? vl.y : vl.x, vl.y};
+            } else {  // (lanes past S accumulate sums nobody reads)
+                dd[x] = r < N ? *reinterpret_cast<const unsigned int*>(D16 + rc * SD + sd) : 0u;
+                vv[x] = *reinterpret_cast<const v2d_t*>(V + rc * S + sc);
+            }
         }
         // ---- the chunk's inner iterations (same arithmetic as k_u_inner_rows16)
         for (int t2 = 0; t2 < n_iter2; ++t2) {
@@ -644,7 +656,7 @@ __global__ __launch_bounds__(256 * NSG) void k_inner_bu(const double* __restrict
         for (int l = 0; l < NU; ++l) {
             double* __restrict__ out = slab + ((int64_t)blockIdx.x * NU + l) * S + s;
             out[0] = acc[l][0];
-            out[1] = acc[l][1];
+            if (!lone) out[1] = acc[l][1];
         }
     }
     __syncthreads();
@@ -661,8 +673,8 @@ __global__ __launch_bounds__(256 * NSG) void k_inner_bu(const double* __restrict
 }
 
 bool u_inner_bu_supported(const double* V, int S, int SD, int n_u, int n_iter2) {
-    return n_u >= 5 && n_u <= 16 && S >= 2 && (S & 1) == 0 && S <= 256 && (SD & 1) == 0 && n_iter2 <= kInnerBuMaxSteps &&
-           (reinterpret_cast<uintptr_t>(V) & 15) == 0;
+    return n_u >= 5 && n_u <= 16 && S >= 2 && S <= 256 && (SD & 1) == 0 && n_iter2 <= kInnerBuMaxSteps &&
+           (reinterpret_cast<uintptr_t>(V) & 7) == 0;
 }
 
 int u_inner_bu_grid(int64_t N, int S) {
@@ -683,14 +695,18 @@ static hipError_t launch_u_inner_bu(const double* cm, double* beta, double* u, d
     const int nsg = S <= 128 ? 1 : 2;
     const int us = n_u + (n_u & 1);
     const size_t lds = ((size_t)((n_iter2 + 1) & ~1) + (size_t)2 * 16 * nsg * us + (size_t)nsg * n_u * 2 * 64) * sizeof(double);
-#define DMF_CASE(NU_)                                                                                                  \
-    case NU_:                                                                                                          \
-        if (nsg == 1)                                                                                                  \
-            hipLaunchKernelGGL((k_inner_bu<NU_, 1>), dim3((unsigned)grid), dim3(256), lds, st, cm, beta, u, u_prev, state, V, \
-                               D16, SD, N, S, n_iter2, mode, slab, u2_partials);                                       \
-        else                                                                                                           \
-            hipLaunchKernelGGL((k_inner_bu<NU_, 2>), dim3((unsigned)grid), dim3(512), lds, st, cm, beta, u, u_prev, state, V, \
-                               D16, SD, N, S, n_iter2, mode, slab, u2_partials);                                       \
+#define DMF_LAUNCH(NU_, NSG_, ODD_)                                                                                      \
+    hipLaunchKernelGGL((k_inner_bu<NU_, NSG_, ODD_>), dim3((unsigned)grid), dim3(256 * NSG_), lds, st, cm, beta, u, u_prev, \
+                       state, V, D16, SD, N, S, n_iter2, mode, slab, u2_partials)
+#define DMF_CASE(NU_)                                     \
+    case NU_:                                             \
+        if (nsg == 1) {                                   \
+            if (S & 1) DMF_LAUNCH(NU_, 1, true);          \
+            else DMF_LAUNCH(NU_, 1, false);               \
+        } else {                                          \
+            if (S & 1) DMF_LAUNCH(NU_, 2, true);          \
+            else DMF_LAUNCH(NU_, 2, false);               \
+        }                                                 \
         break;
     switch (n_u) {
         DMF_CASE(5) DMF_CASE(6) DMF_CASE(7) DMF_CASE(8) DMF_CASE(9) DMF_CASE(10) DMF_CASE(11) DMF_CASE(12) DMF_CASE(13)
@@ -698,6 +714,7 @@ static hipError_t launch_u_inner_bu(const double* cm, double* beta, double* u, d
         default: return hipErrorInvalidValue;
     }
 #undef DMF_CASE
+#undef DMF_LAUNCH
     return hipGetLastError();
 }
 

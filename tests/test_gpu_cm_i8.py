@@ -142,3 +142,35 @@ def test_more_inner_steps_than_the_fused_kernel_holds(ctx):
     wu, wa = osol.solve_partial(u0.copy(), R, a0.copy(), V, D, Rt, 5, 2, 1100, 0.0, project=osol.simplex_project_columns_fast)
     gu, ga = dd.mdwbssmf_deconv(u0, R, a0, V, D, Rt, 5, n_iter1=2, n_iter2=1100, tol=0.0)
     assert rel_err(ga, wa) < TIGHT and np.abs(gu - wu).max() < TIGHT
+
+
+# odd sample counts: rows of V start 8 bytes off a 16-byte boundary every other time, the row's last sample has no partner
+# (every integer-count kernel takes samples in pairs or fours): second-generation kernels throughout
+ODD_S_CASES = [
+    (2000, 255, 12, 4, 3, 40, ["rowpass=k_rowpass_v2<3,4>", "nw=4", "gram=k_gram_i8<nd=1>"], "the headline instantiation, one sample short"),
+    (4096 + 5, 129, 6, 3, 3, 40, ["rowpass=k_rowpass_v2<2,3>", "nw=3", "gram=k_gram_i8<nd=1>"], "third column group holds one sample"),
+    (1000, 33, 0, 2, 4, 900, ["rowpass=k_rowpass_v2<0,2>", "gram=k_gram_i8<nd=2>"], "unsupervised, two count digit planes"),
+    (5, 7, 2, 1, 5, 40, ["rowpass=k_rowpass_v2<1,1>"], "five rows, seven samples"),
+    (333, 3, 1, 1, 4, 40, ["rowpass=k_rowpass_v2<1,1>"], "three samples"),
+    (1500, 127, 0, 8, 3, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "wide row groups: the last group of four holds three samples"),
+    (900, 255, 4, 6, 2, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "four column groups, eight-wave k_inner_bu"),
+    (700, 5, 3, 5, 3, 40, ["k_cm_i8<nd=1>+k_inner_bu"], "five samples: one group of four and one lone sample"),
+    (650, 67, 0, 12, 2, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "second column group holds three samples"),
+    (800, 201, 12, 9, 2, 3000, ["k_cm_i8<nd=2>+k_inner_bu", "gram=k_gram_i8<nd=2>"], "S = 1 mod 4, two count digit planes, known types"),
+]
+
+
+@pytest.mark.parametrize("N,S,n_c,n_u,T1,depth,expect,why", ODD_S_CASES)
+def test_odd_sample_counts_against_oracle(ctx, N, S, n_c, n_u, T1, depth, expect, why):
+    from demethify_amd import _lib as L
+
+    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=37, depth=depth)
+    D[::6, ::4] = 0
+    V = np.where(D == 0, 0.0, V)
+    u0, a0, wu, wa = _oracle(V, D, Rt, n_c, n_u, T1, seed=6)
+    mode = L.DMF_MODE_PARTIAL if n_c else L.DMF_MODE_UNSUPERVISED
+    u, alpha, cost, direct, _ = _solve_at_level(ctx, 0, V, D, Rt if n_c else None, u0, a0, mode, T1, expect)
+    assert rel_err(alpha, wa) < TIGHT and np.abs(alpha - wa).max() < TIGHT, why
+    assert np.abs(u - wu).max() < TIGHT, why
+    want = osol.weighted_cost(V, np.c_[Rt, wu] if n_c else wu, wa, D)
+    assert cost == pytest.approx(want, rel=1e-9) and direct == pytest.approx(want, rel=1e-11)
