@@ -174,3 +174,24 @@ def test_odd_sample_counts_against_oracle(ctx, N, S, n_c, n_u, T1, depth, expect
     assert np.abs(u - wu).max() < TIGHT, why
     want = osol.weighted_cost(V, np.c_[Rt, wu] if n_c else wu, wa, D)
     assert cost == pytest.approx(want, rel=1e-9) and direct == pytest.approx(want, rel=1e-11)
+
+
+@pytest.mark.parametrize("S,n_c,n_u", [(131, 5, 3), (77, 0, 7)])
+def test_resampled_problem_with_odd_sample_count(ctx, S, n_c, n_u):
+    """bootstrap.py:28: a row resample of an odd-S problem (dmf_problem_gather gathers the u16 counts too) solved on the
+    second-generation kernels against the oracle on the fancy-indexed arrays."""
+    from demethify_amd import _lib as L
+    from demethify_amd.device import Problem, Solver
+
+    N, T1 = 1200, 3
+    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=51, depth=45)
+    idx = osol.bootstrap_indices(17, N)
+    Vg, Dg, Rg = V[idx], D[idx], Rt[idx]
+    u0, a0, wu, wa = _oracle(Vg, Dg, Rg, n_c, n_u, T1, seed=8)
+    mode = L.DMF_MODE_PARTIAL if n_c else L.DMF_MODE_UNSUPERVISED
+    with Problem(ctx, V, D, Rt if n_c else None) as p, p.gather(idx) as g, Solver(g, u0, a0, mode) as s:
+        path = s.describe(20)
+        assert ("k_rowpass_v2" in path) if n_u <= 4 else ("k_cm_i8" in path), path
+        s.step(T1, 20, 0.0)
+        u, alpha, _, _ = s.get()
+    assert np.abs(alpha - wa).max() < TIGHT and np.abs(u - wu).max() < TIGHT
