@@ -99,8 +99,11 @@ __device__ __forceinline__ void inner_steps(double& uu, double& up, double cj, c
     }
 }
 
-template <int NKC, int NU>
-__global__ __launch_bounds__(256, 2) void k_rowpass_v2(
+// MAXW: most waves (64-sample column groups) a workgroup may have.  4: S <= 256, two workgroups per CU.  8: S <= 512, ONE
+// workgroup of up to eight waves per CU -- nothing hides its phase B, but a block then carries twice the samples, so the
+// time per element is that of the four-wave form (measured: DESIGN.md section 5).
+template <int NKC, int NU, int MAXW = 4>
+__global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
     const double* __restrict__ V, const unsigned short* __restrict__ D16, int SD, const double* __restrict__ Rtp,
     const double* __restrict__ alpha, double* __restrict__ u, double* __restrict__ u_prev,
     const SolverState* __restrict__ state, int64_t N, int S, int n_c, int n_iter2, int mode, int nd,
@@ -121,13 +124,13 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
     const int lane = threadIdx.x & 63;
     const int wcol0 = wave * 64;
 
-    // LDS carve-up (doubles unless noted): beta[n_iter2 (even)] | ubuf[16][NU] | red[NW][NV][16] | u2[4] |
+    // LDS carve-up (doubles unless noted): beta[n_iter2 (even)] | ubuf[16][NU] | red[NW][NV][16] | u2[MAXW] |
     //   tiles[NW]{ V f64 [16][66], D f32 [16][68] }
     double* __restrict__ beta_tab = lds_dyn;
     double* __restrict__ ubuf = beta_tab + ((n_iter2 + 1) & ~1);
     double* __restrict__ red = ubuf + 16 * NU;
     double* __restrict__ u2red = red + NW * NV * 16;
-    char* __restrict__ tile = reinterpret_cast<char*>(u2red + 4) + (size_t)wave * kTileBytes2;
+    char* __restrict__ tile = reinterpret_cast<char*>(u2red + MAXW) + (size_t)wave * kTileBytes2;
     double* __restrict__ tileV = reinterpret_cast<double*>(tile);
     float* __restrict__ tileD = reinterpret_cast<float*>(tile + kTileVBytes2);
     char* __restrict__ tileB = tile + kTileVBytes2 + kTileDBytes2;  // [2 digit planes][16][kRowB]: counts as balanced bytes
@@ -512,43 +515,46 @@ __global__ __launch_bounds__(256, 2) void k_rowpass_v2(
 size_t rowpass_v2_lds_bytes(int S, int n_u, int n_iter2) {
     const int NW = (S + 63) / 64;
     const int nv = n_u + n_u * (n_u + 1) / 2;
-    const size_t doubles = (size_t)((n_iter2 + 1) & ~1) + 16 * n_u + (size_t)NW * nv * 16 + 4;
+    const size_t doubles = (size_t)((n_iter2 + 1) & ~1) + 16 * n_u + (size_t)NW * nv * 16 + (NW <= 4 ? 4 : 8);
     return doubles * sizeof(double) + (size_t)NW * kTileBytes2;
 }
 
 bool rowpass_v2_supported(int S, int n_c, int n_u, int n_iter2) {
-    if (S < 2 || S > 256 || n_c > 16 || n_u < 1 || n_u > 4) return false;
-    return rowpass_v2_lds_bytes(S, n_u, n_iter2) <= 80 * 1024;  // two workgroups per CU within 160 KB
+    if (S < 2 || S > 512 || n_c > 16 || n_u < 1 || n_u > 4) return false;
+    // up to 256 samples: two workgroups per CU within 160 KB; beyond: one workgroup of up to eight waves
+    return rowpass_v2_lds_bytes(S, n_u, n_iter2) <= (size_t)(S <= 256 ? 80 : 160) * 1024;
 }
 
 int rowpass_v2_grid(int64_t N, int S) {
     const int NW = (S + 63) / 64;
-    int per_cu = 8 / NW;  // two waves per SIMD: NW = 4 -> 2, 3 -> 2, 2 -> 4, 1 -> 8 workgroups per CU
+    int per_cu = NW > 4 ? 1 : 8 / NW;  // two waves per SIMD: NW = 5..8 -> 1, 4 -> 2, 3 -> 2, 2 -> 4, 1 -> 8 workgroups per CU
     if (const char* v = getenv("DMF_V2_PER_CU")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (experiments)
     const int64_t nblk = (N + 15) / 16;
     const int64_t g = 256 * per_cu;
     return (int)(nblk < g ? nblk : g);
 }
 
-template <int NKC, int NU>
+template <int NKC, int NU, int MAXW>
 static hipError_t launch_v2_t(const double* V, const unsigned short* D16, int SD, const double* Rtp, const double* alpha,
                               double* u, double* u_prev, SolverState* state, int64_t N, int S, int n_c, int n_iter2,
                               int mode, int nd, double* slab, double* u2_partials, int* grid_out, hipStream_t st) {
     const int NW = (S + 63) / 64;
     const size_t lds = rowpass_v2_lds_bytes(S, NU, n_iter2);
-    if (lds > 80 * 1024 || N < 1 || SD < NW * 64 || (SD & 7) != 0 || nd < 1 || nd > 2) return hipErrorInvalidValue;
+    constexpr size_t kLdsCap = (size_t)(MAXW == 4 ? 80 : 160) * 1024;
+    if (NW > MAXW || (MAXW == 8 && NW <= 4) || lds > kLdsCap || N < 1 || SD < NW * 64 || (SD & 7) != 0 || nd < 1 || nd > 2)
+        return hipErrorInvalidValue;
     static bool lds_limit_raised[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (lds > 48 * 1024 && !lds_limit_raised[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_rowpass_v2<NKC, NU>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           80 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_rowpass_v2<NKC, NU, MAXW>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCap);
         if (e != hipSuccess) return e;
         lds_limit_raised[dev] = true;
     }
     const int grid = rowpass_v2_grid(N, S);
     *grid_out = grid;
-    hipLaunchKernelGGL((k_rowpass_v2<NKC, NU>), dim3(grid), dim3(NW * 64), lds, st, V, D16, SD, Rtp, alpha, u, u_prev,
+    hipLaunchKernelGGL((k_rowpass_v2<NKC, NU, MAXW>), dim3(grid), dim3(NW * 64), lds, st, V, D16, SD, Rtp, alpha, u, u_prev,
                        state, N, S, n_c, n_iter2, mode, nd, slab, u2_partials
 #ifdef DMF_STAMPS
                        , (unsigned long long*)nullptr
@@ -563,10 +569,12 @@ static hipError_t launch_v2_nkc(int n_u, const double* V, const unsigned short* 
                                 int n_c, int n_iter2, int mode, int nd, double* slab, double* u2_partials, int* grid_out,
                                 hipStream_t st) {
     switch (n_u) {
-#define DMF_CASE(NU_)                                                                                            \
-    case NU_:                                                                                                    \
-        return launch_v2_t<NKC, NU_>(V, D16, SD, Rtp, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, nd, slab, \
-                                     u2_partials, grid_out, st);
+#define DMF_CASE(NU_)                                                                                                   \
+    case NU_:                                                                                                           \
+        return S <= 256 ? launch_v2_t<NKC, NU_, 4>(V, D16, SD, Rtp, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, nd, \
+                                                   slab, u2_partials, grid_out, st)                                     \
+                        : launch_v2_t<NKC, NU_, 8>(V, D16, SD, Rtp, alpha, u, u_prev, state, N, S, n_c, n_iter2, mode, nd, \
+                                                   slab, u2_partials, grid_out, st);
         DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4)
 #undef DMF_CASE
         default: return hipErrorInvalidValue;

@@ -239,18 +239,26 @@ def test_in_launch_hand_overs_are_race_free(ctx, N, S, n_c, n_u, depth):
                 np.testing.assert_array_equal(u, first[0], err_msg=f"repetition {rep}")
 
 
-@pytest.mark.parametrize("N,S,n_c,n_u", [(3000, 320, 12, 4), (2500, 512, 10, 5)])
-def test_beyond_256_samples_integer_gram_behind_the_row_kernels(ctx, N, S, n_c, n_u):
-    """S > 256: the second-generation row pass does not take the shape, but the integer Gram (with the b_u stream kernel)
-    and the u16 cost kernel do -- the u phase runs on the first-generation MFMA kernels."""
+@pytest.mark.parametrize("N,S,n_c,n_u,depth,expect", [
+    (3000, 320, 12, 4, 40, ["rowpass=k_rowpass_v2<3,4>", "nw=5", "gram=k_gram_i8<nd=1>"]),
+    (2100, 512, 12, 4, 40, ["rowpass=k_rowpass_v2<3,4>", "nw=8", "gram=k_gram_i8<nd=1>"]),
+    (1500, 449, 0, 1, 40, ["rowpass=k_rowpass_v2<0,1>", "nw=8"]),
+    (1234, 384, 16, 3, 2500, ["rowpass=k_rowpass_v2<4,3>", "nw=6", "gram=k_gram_i8<nd=2>"]),
+    (2500, 512, 10, 5, 40, ["rowpass=k_u_phase_mfma", "gram=k_bu_cols+k_gram_i8<nd=1>"]),
+    (1800, 640, 6, 2, 40, ["rowpass=k_u_phase_gram"]),  # beyond 512 samples: the any-shape kernels
+])
+def test_beyond_256_samples(ctx, N, S, n_c, n_u, depth, expect):
+    """257..512 samples with up to four unknowns: the second-generation row pass as ONE workgroup of up to eight waves per
+    CU.  Wider row groups or more samples: the u phase on the first-generation MFMA kernels, with the integer Gram (b_u
+    stream kernel) and the u16 cost kernel behind them."""
     from demethify_amd import _lib as L
 
-    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=11, depth=40)
+    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=11, depth=depth)
     T1 = 3
     u0, a0, wu, wa = _oracle(V, D, Rt, n_c, n_u, T1, seed=2)
-    u, alpha, cost, direct, path = _solve_at_level(ctx, 0, V, D, Rt, u0, a0, L.DMF_MODE_PARTIAL, T1,
-                                                   ["rowpass=k_u_phase_mfma", "gram=k_bu_cols+k_gram_i8<nd=1>"])
+    mode = L.DMF_MODE_PARTIAL if n_c else L.DMF_MODE_UNSUPERVISED
+    u, alpha, cost, direct, path = _solve_at_level(ctx, 0, V, D, Rt if n_c else None, u0, a0, mode, T1, expect)
     assert rel_err(alpha, wa) < TIGHT and np.abs(alpha - wa).max() < TIGHT
     assert np.abs(u - wu).max() < TIGHT
-    want = osol.weighted_cost(V, np.c_[Rt, wu], wa, D)
+    want = osol.weighted_cost(V, np.c_[Rt, wu] if n_c else wu, wa, D)
     assert cost == pytest.approx(want, rel=1e-9) and direct == pytest.approx(want, rel=1e-11)

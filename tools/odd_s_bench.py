@@ -12,7 +12,7 @@ from demethify_amd.device import Context, Problem, Solver
 
 dev = torch.device("cuda", 0)
 ctx = Context(0)
-for N, S, n_c, n_u in [(1_000_000, 255, 12, 4), (1_000_000, 256, 12, 4), (500_000, 127, 0, 8), (500_000, 128, 0, 8), (100_000, 63, 6, 2)]:
+for N, S, n_c, n_u in [(1_000_000, 255, 12, 4), (1_000_000, 256, 12, 4), (500_000, 127, 0, 8), (500_000, 128, 0, 8), (100_000, 63, 6, 2), (500_000, 512, 12, 4), (500_000, 384, 12, 4)]:
     V, D, Rt = make_inputs_on_device(torch, dev, N, S, max(n_c, 1), n_u, seed=0)
     rs = np.random.RandomState(1)
     u0 = rs.uniform(size=(N, n_u)); a0 = rs.dirichlet(np.ones(n_c + n_u), S).T
