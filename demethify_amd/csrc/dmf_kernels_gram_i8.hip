@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void k_bu_cols(const double* __restrict__ V, c
     }
 }
 
-// The same stream with TWO adjacent samples per lane (S even, 16-byte aligned V): one 16-byte load of V and one 4-byte
+// The same stream with TWO adjacent samples per lane (odd S: see `lone`): one 16-byte load of V and one 4-byte
 // load of the counts per row and lane -- half the load instructions per byte (the 2-byte-per-lane count load of the form
 // above is the worst shape for the load path).  Same per-element arithmetic; slab layout unchanged.
 template <int NU>
@@ -542,8 +542,13 @@ __global__ __launch_bounds__(256) void k_bu_cols2(const double* __restrict__ V, 
     if (done_flag != nullptr && *done_flag) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int s = blockIdx.y * 128 + 2 * lane;
-    const bool active = s < S;  // (S even: both samples or none)
-    const int sc = active ? s : S - 2;
+    const bool active = s < S;
+    // odd S: the row's lone last sample takes the upper half of the pair one element lower; its partner's count is zero
+    // padding (as in k_cost_cols2)
+    const bool lone = s == S - 1;
+    const int sc = lone ? S - 2 : (active ? s : 0);
+    const int sd = active ? s : 0;
+    typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
     double acc[NU][2];
 #pragma unroll
     for (int j = 0; j < NU; ++j) acc[j][0] = acc[j][1] = 0.0;
@@ -555,9 +560,9 @@ __global__ __launch_bounds__(256) void k_bu_cols2(const double* __restrict__ V, 
         for (int x = 0; x < kRows; ++x) {
             const int64_t i = i0 + x * stride;
             row[x] = i < N ? i : N - 1;
-            const unsigned int dd = i < N ? *reinterpret_cast<const unsigned int*>(D16 + row[x] * SD + sc) : 0u;
-            const v2d v = *reinterpret_cast<const v2d*>(V + row[x] * S + sc);
-            t0[x] = (double)(dd & 0xFFFFu) * v.x;
+            const unsigned int dd = i < N ? *reinterpret_cast<const unsigned int*>(D16 + row[x] * SD + sd) : 0u;
+            const v2d_u v = *reinterpret_cast<const v2d_u*>(V + row[x] * S + sc);
+            t0[x] = (double)(dd & 0xFFFFu) * (lone ? v.y : v.x);
             t1[x] = (double)(dd >> 16) * v.y;
         }
 #pragma unroll
@@ -584,7 +589,7 @@ __global__ __launch_bounds__(256) void k_bu_cols2(const double* __restrict__ V, 
         for (int j = 0; j < NU; ++j) {
             double* __restrict__ out = slab + ((int64_t)blockIdx.x * NU + j) * S + s;
             out[0] = ((acc[j][0] + red[0][j][0][lane]) + red[1][j][0][lane]) + red[2][j][0][lane];
-            out[1] = ((acc[j][1] + red[0][j][1][lane]) + red[1][j][1][lane]) + red[2][j][1][lane];
+            if (!lone) out[1] = ((acc[j][1] + red[0][j][1][lane]) + red[1][j][1][lane]) + red[2][j][1][lane];
         }
     }
 }
@@ -600,7 +605,7 @@ hipError_t launch_bu_cols(const double* V, const unsigned short* D16, int SD, co
     const int nbx = bu_cols_grid(N);
     *n_slabs_out = nbx;
     const dim3 block(256);
-    if ((S & 1) == 0 && (SD & 1) == 0 && S >= 128 && n_u <= 16 && (reinterpret_cast<uintptr_t>(V) & 15) == 0) {
+    if ((SD & 1) == 0 && S >= 128 && n_u <= 16 && (reinterpret_cast<uintptr_t>(V) & 7) == 0) {
         const dim3 grid2(nbx, (S + 127) / 128);
         switch (n_u) {  // (LDS for the cross-wave sum: 3 x NU x 2 x 64 doubles = 48 KB at sixteen unknowns)
 #define DMF_CASE2(NU_) \

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_cost_cols(const double* __restrict__ V,
     if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
 }
 
-// The same kernel with TWO adjacent samples per lane (S even, 16-B aligned V, the u16 count copy): one 16-byte load of V
+// The same kernel with TWO adjacent samples per lane (the u16 count copy; odd S: see `lone`): one 16-byte load of V
 // and one 4-byte load of the counts per row and lane instead of 8 + 2 bytes -- half the load instructions per byte.
 // The headline shape streams 2.56 GB per evaluation; the one-sample form reached 3.9 TB/s, 62 % of what a plain copy
 // gets on this part.  Per-element arithmetic as above; a lane's two samples have an accumulator each.
@@ -280,17 +280,27 @@ __global__ __launch_bounds__(256) void k_cost_cols2(const double* __restrict__ V
     __shared__ double red[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int s = blockIdx.y * 128 + 2 * lane;
-    const bool active = s < S;  // (S is even: both samples or none)
-    const int sc = active ? s : S - 2;
+    const bool active = s < S;
+    // odd S: the row's last sample sits alone in its lane -- it takes the upper half of the pair one element lower (never
+    // past the end of a row), its partner's count is the zero padding of the u16 copy; rows of V then start 8 bytes off a
+    // 16-byte boundary every other time, which 16-byte loads take (tools/align_probe.hip)
+    const bool lone = s == S - 1;
+    const int sc = lone ? S - 2 : (active ? s : 0);  // V / alpha column of the pair fetched
+    const int sd = active ? s : 0;                   // count pair (4-byte aligned: s is even)
+    typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
     double ak[NCT > 0 ? NCT : 1][2], aj[NU > 0 ? NU : 1][2];
 #pragma unroll
-    for (int k = 0; k < NCT; ++k)
+    for (int k = 0; k < NCT; ++k) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) ak[k][h] = k < n_c ? alpha[(int64_t)k * S + sc + h] : 0.0;
+        if (lone) ak[k][0] = ak[k][1];
+    }
 #pragma unroll
-    for (int j = 0; j < NU; ++j)
+    for (int j = 0; j < NU; ++j) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) aj[j][h] = alpha[(int64_t)(n_c + j) * S + sc + h];
+        if (lone) aj[j][0] = aj[j][1];
+    }
     double acc0 = 0.0, acc1 = 0.0;
     const int64_t stride = (int64_t)gridDim.x * 4;
     for (int64_t i0 = (int64_t)blockIdx.x * 4 + wave; i0 < N; i0 += kRows * stride) {
@@ -301,8 +311,9 @@ __global__ __launch_bounds__(256) void k_cost_cols2(const double* __restrict__ V
         for (int x = 0; x < kRows; ++x) {
             const int64_t i = i0 + x * stride;
             row[x] = i < N ? i : N - 1;
-            v[x] = *reinterpret_cast<const v2d*>(V + row[x] * S + sc);
-            dd[x] = *reinterpret_cast<const unsigned int*>(Dh + row[x] * SD + sc);
+            const v2d_u vl = *reinterpret_cast<const v2d_u*>(V + row[x] * S + sc);
+            v[x] = v2d{lone ? vl.y : vl.x, vl.y};
+            dd[x] = *reinterpret_cast<const unsigned int*>(Dh + row[x] * SD + sd);
             if (i >= N) dd[x] = 0u;  // rows past N weigh nothing
         }
 #pragma unroll
@@ -405,7 +416,7 @@ static hipError_t launch_cost_cols_t(const double* V, const double* D, const uns
     int nbx = (int)(want < 1 ? 1 : want);
     const int cap = 1024 / ny;  // scratch: 1024 partials
     if (nbx > cap) nbx = cap;
-    if (D16 != nullptr && S % 2 == 0 && S >= 128 && SD % 2 == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0) {
+    if (D16 != nullptr && S >= 128 && SD % 2 == 0 && (reinterpret_cast<uintptr_t>(V) & 7) == 0) {
         const int ny2 = (S + 127) / 128;
         nbx = (int)(want < 1 ? 1 : want);
         if (nbx > 1024 / ny2) nbx = 1024 / ny2;
@@ -452,8 +463,9 @@ hipError_t launch_cost_cols(const double* V, const double* D, const unsigned sho
 // Wide row groups (5..16 unknowns): the two-samples-per-lane form only (u16 counts, S even and >= 128, 16-B aligned V);
 // other shapes of that width stay on the generic k_cost.
 bool cost_cols2_wide_supported(const double* V, const unsigned short* D16, int S, int SD, int n_c, int n_u) {
-    return D16 != nullptr && n_c <= 16 && n_u >= 5 && n_u <= 16 && S % 2 == 0 && S >= 128 && SD % 2 == 0 &&
-           (reinterpret_cast<uintptr_t>(V) & 15) == 0;
+    // (below 128 samples part of the lanes idle; what competes is the any-shape k_cost, slower from ~32 samples on)
+    return D16 != nullptr && n_c <= 16 && n_u >= 5 && n_u <= 16 && S >= 32 && SD % 2 == 0 &&
+           (reinterpret_cast<uintptr_t>(V) & 7) == 0;
 }
 
 template <int NKC, int NU>

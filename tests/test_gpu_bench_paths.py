@@ -245,6 +245,7 @@ def test_in_launch_hand_overs_are_race_free(ctx, N, S, n_c, n_u, depth):
     (1500, 449, 0, 1, 40, ["rowpass=k_rowpass_v2<0,1>", "nw=8"]),
     (1234, 384, 16, 3, 2500, ["rowpass=k_rowpass_v2<4,3>", "nw=6", "gram=k_gram_i8<nd=2>"]),
     (2500, 512, 10, 5, 40, ["rowpass=k_u_phase_mfma", "gram=k_bu_cols+k_gram_i8<nd=1>"]),
+    (1700, 321, 10, 5, 40, ["rowpass=k_u_phase_mfma", "gram=k_bu_cols+k_gram_i8<nd=1>"]),  # odd S in k_bu_cols2 / k_cost_cols2
     (1800, 640, 6, 2, 40, ["rowpass=k_u_phase_gram"]),  # beyond 512 samples: the any-shape kernels
 ])
 def test_beyond_256_samples(ctx, N, S, n_c, n_u, depth, expect):
