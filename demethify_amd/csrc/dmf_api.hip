@@ -976,7 +976,8 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     // Wide row groups (n_u 5..16) on u16 counts: the split u phase with the integer-matrix-core producer.  Measured at
     // 5e5 x 128 against what ran before: see DESIGN.md section 5.  DMF_CM_I8_MIN_NU moves the lower end (experiments).
     static const int cm_min_nu = [] { const char* v = getenv("DMF_CM_I8_MIN_NU"); return v != nullptr && atoi(v) > 0 ? atoi(v) : 5; }();
-    s->use_cm_i8 = ctx->generic_level == 0 && !s->use_v2 && p->ND > 0 && p->D16 != nullptr && n_u >= cm_min_nu && n_u <= 16 &&
+    // (narrow row groups reach it beyond the row pass's 512 samples: the producer walks panels of 256 samples)
+    s->use_cm_i8 = ctx->generic_level == 0 && !s->use_v2 && p->ND > 0 && p->D16 != nullptr && (n_u >= cm_min_nu || S > 512) && n_u <= 16 &&
                    (n_c == 0 || (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 7) == 0)) &&
                    dmf::cm_i8_supported(p->V, (int)S, (int)n_c, (int)n_u, p->ND, p->SD);
     // shapes the second-generation row pass does not take (n_u 5..20, long inner loops): the u phase stays a kernel of its

@@ -59,13 +59,16 @@ template <int NKC, int ND, int NCGX, bool S4>
 __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, const unsigned short* __restrict__ D16, int SD,
                                                const double* __restrict__ Rtp, const double* __restrict__ alpha,
                                                const SolverState* __restrict__ state, int64_t N, int S, int n_c, int n_u,
-                                               double* __restrict__ cm_out) {
+                                               double* __restrict__ cm_out, int col0, int Sp, int accumulate) {
+    // A launch covers the PANEL of samples col0 .. col0 + Sp - 1 (Sp <= 256) of rows that are S samples long; beyond 256
+    // samples the launcher walks the panels and every launch but the first adds to what is in cm_out (a wave owns its
+    // rows, the panels follow each other on the stream: fixed summation order).
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (state->done) return;
     constexpr int NWT = 7 + ND - 1;  // digit weights 256^0 .. 256^(NWT-1)
     const int NP = n_u * (n_u + 1) / 2, NV = n_u + NP;
-    const int nmt = (NP + 15) / 16, ncg = (S + 63) / 64;
-    const CmLayout L = cm_layout(S, n_c, n_u);
+    const int nmt = (NP + 15) / 16, ncg = (Sp + 63) / 64;
+    const CmLayout L = cm_layout(Sp, n_c, n_u);
     v4i* __restrict__ pd = reinterpret_cast<v4i*>(lds_raw);
     double* __restrict__ alds = reinterpret_cast<double*>(lds_raw + (size_t)L.pd_dwords4 * 16);
     const int AS = L.AS;
@@ -75,13 +78,13 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
     const int m16 = lane & 15, q = lane >> 4;
 
     // ---- workgroup tables -------------------------------------------------------------------------------------
-    // alpha copy: rows 0 .. 4 NKC - 1 = -alpha_known (zero rows past n_c), then alpha_unk; zero for samples >= S
+    // alpha copy: rows 0 .. 4 NKC - 1 = -alpha_known (zero rows past n_c), then alpha_unk; zero past the panel
     for (int i = threadIdx.x; i < L.n_rows * AS; i += kCmWaves * 64) {
         const int r = i / AS, c = i - r * AS;
         double val = 0.0;
-        if (c < S) {
-            if (r < 4 * NKC) val = r < n_c ? -alpha[(int64_t)r * S + c] : 0.0;
-            else val = alpha[(int64_t)(n_c + r - 4 * NKC) * S + c];
+        if (c < Sp) {
+            if (r < 4 * NKC) val = r < n_c ? -alpha[(int64_t)r * S + col0 + c] : 0.0;
+            else val = alpha[(int64_t)(n_c + r - 4 * NKC) * S + col0 + c];
         }
         alds[i] = val;
     }
@@ -101,9 +104,9 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int col = 64 * cg + 16 * g + 4 * q + i;
-                const bool in = pair_ok && col < S;
-                const double aj = in ? alpha[(int64_t)(n_c + pj) * S + col] : 0.0;
-                const double al = in ? alpha[(int64_t)(n_c + pl) * S + col] : 0.0;
+                const bool in = pair_ok && col < Sp;
+                const double aj = in ? alpha[(int64_t)(n_c + pj) * S + col0 + col] : 0.0;
+                const double al = in ? alpha[(int64_t)(n_c + pl) * S + col0 + col] : 0.0;
                 z_to_biased(aj, al, lo[i], hi[i]);
             }
             transpose4(lo, tl);
@@ -139,8 +142,9 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
     typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
     auto load_strip = [&](int64_t rowc, int cg, int t, v4d& e, unsigned long long& d) {
         int c = 64 * cg + 16 * t + 4 * q;
-        if constexpr (S4) {  // S % 4 == 0: a lane's four samples are all in range or all out
-            const double* __restrict__ vp = V + rowc * S + (c < S ? c : 0);
+        if constexpr (S4) {  // panel width % 4 == 0 (and S even): a lane's four samples are all in range or all out
+            if constexpr (NCGX > 2) asm volatile("" : "+v"(c));  // (sixteen hoisted strip addresses spill; see below)
+            const double* __restrict__ vp = V + rowc * S + col0 + (c < Sp ? c : 0);
             const v2d v01 = *reinterpret_cast<const v2d*>(vp);
             const v2d v23 = *reinterpret_cast<const v2d*>(vp + 2);
             e = v4d{v01.x, v01.y, v23.x, v23.y};
@@ -148,17 +152,18 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
             // (recomputed at every use: hoisted out of the row loop, the per-strip lane constants below cost the kernel 30
             // to 60 registers and, with four column groups, spills)
             asm volatile("" : "+v"(c));
-            const int left = S - c;
+            const int left = Sp - c;
             const int cb = left > 0 ? c : 0;
-            const int nvb = left > 0 ? left : S;  // samples of the group read that exist (>= 1; S >= 2)
-            const int o01 = nvb >= 2 ? 0 : -1;    // one sample: the pair (cb - 1, cb)
+            const int nvb = left > 0 ? left : Sp;  // samples of the group read that exist (>= 1)
+            const int o01 = nvb >= 2 ? 0 : -1;     // one sample: the pair (cb - 1, cb) -- inside the row: S >= 2, and a
+                                                   // one-sample panel is never the row's first
             const int o23 = nvb >= 4 ? 2 : (nvb == 3 ? 1 : o01);  // three: (cb + 1, cb + 2); fewer: the first pair again
-            const double* __restrict__ vp = V + rowc * S + cb;
+            const double* __restrict__ vp = V + rowc * S + col0 + cb;
             const v2d_u v01 = *reinterpret_cast<const v2d_u*>(vp + o01);
             const v2d_u v23 = *reinterpret_cast<const v2d_u*>(vp + o23);
             e = v4d{nvb >= 2 ? v01.x : v01.y, v01.y, nvb == 3 ? v23.y : v23.x, v23.y};
         }
-        d = *reinterpret_cast<const unsigned long long*>(D16 + rowc * SD + (64 * cg + 16 * t + 4 * q));
+        d = *reinterpret_cast<const unsigned long long*>(D16 + rowc * SD + col0 + (64 * cg + 16 * t + 4 * q));
     };
 
     v4d nv[4];
@@ -259,7 +264,10 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
             if (row < N) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (q + 4 * r < n_u) cm_out[row * NV + q + 4 * r] = cacc[h][r];
+                    if (q + 4 * r < n_u) {
+                        double* __restrict__ dst = cm_out + row * NV + q + 4 * r;
+                        *dst = accumulate ? *dst + cacc[h][r] : cacc[h][r];
+                    }
             }
         }
 
@@ -305,7 +313,10 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
                         if constexpr (ND == 2) hi = fma((double)acc[h][7][rr], 16777216.0, hi);
                         const double m = fma(hi, 0x1p32, lo) * 0x1p-52;
                         const int64_t row = row00 + 16 * (h0 + h) + 4 * q + rr;
-                        if (p < NP && row < N) cm_out[row * NV + n_u + p] = m;
+                        if (p < NP && row < N) {
+                            double* __restrict__ dst = cm_out + row * NV + n_u + p;
+                            *dst = accumulate ? *dst + m : m;
+                        }
                     }
                 }
             }
@@ -313,18 +324,21 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
     }
 }
 
+constexpr int kCmPanel = 256;  // samples per launch
+
 bool cm_i8_supported(const double* V, int S, int n_c, int n_u, int ND, int SD) {
     if (n_u < 1 || n_u > 16 || n_c < 0 || n_c > 16) return false;
-    if (S < 2 || S > 256 || (SD & 3) != 0 || SD < (S + 63) / 64 * 64) return false;
+    if (S < 2 || S > 1024 || (SD & 3) != 0 || SD < (S + 63) / 64 * 64) return false;
     if (ND != 1 && ND != 2) return false;
     if ((reinterpret_cast<uintptr_t>(V) & 7) != 0) return false;
-    return cm_layout(S, n_c, n_u).bytes <= 160 * 1024;
+    return cm_layout(S < kCmPanel ? S : kCmPanel, n_c, n_u).bytes <= 160 * 1024;
 }
 
 template <int NKC, int ND, int NCGX, bool S4>
 static hipError_t launch_cm_t(const double* V, const unsigned short* D16, int SD, const double* Rtp, const double* alpha,
-                              const SolverState* state, int64_t N, int S, int n_c, int n_u, double* cm, hipStream_t st) {
-    const size_t lds = cm_layout(S, n_c, n_u).bytes;
+                              const SolverState* state, int64_t N, int S, int n_c, int n_u, double* cm, int col0, int Sp,
+                              hipStream_t st) {
+    const size_t lds = cm_layout(Sp, n_c, n_u).bytes;
     static bool raised[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -342,18 +356,19 @@ static hipError_t launch_cm_t(const double* V, const unsigned short* D16, int SD
     const int64_t cap = (int64_t)256 * per_cu;
     const int64_t grid = want < cap ? want : cap;
     hipLaunchKernelGGL((k_cm_i8<NKC, ND, NCGX, S4>), dim3((unsigned)grid), dim3(kCmWaves * 64), lds, st, V, D16, SD, Rtp, alpha,
-                       state, N, S, n_c, n_u, cm);
+                       state, N, S, n_c, n_u, cm, col0, Sp, col0 > 0 ? 1 : 0);
     return hipGetLastError();
 }
 
 template <int NKC>
 static hipError_t launch_cm_nkc(const double* V, const unsigned short* D16, int SD, int ND, const double* Rtp,
                                 const double* alpha, const SolverState* state, int64_t N, int S, int n_c, int n_u,
-                                double* cm, hipStream_t st) {
-    const bool wide = S > 128;
-#define DMF_CM(ND_, NCGX_)                                                                                               \
-    return (S & 3) == 0 ? launch_cm_t<NKC, ND_, NCGX_, true>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, st)     \
-                        : launch_cm_t<NKC, ND_, NCGX_, false>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, st)
+                                double* cm, int col0, int Sp, hipStream_t st) {
+    const bool wide = Sp > 128;
+    const bool s4 = (Sp & 3) == 0 && (S & 1) == 0;  // (odd S: rows of V are 8-byte aligned only)
+#define DMF_CM(ND_, NCGX_)                                                                                                  \
+    return s4 ? launch_cm_t<NKC, ND_, NCGX_, true>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st)          \
+              : launch_cm_t<NKC, ND_, NCGX_, false>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st)
     if (ND == 1) {
         if (wide) DMF_CM(1, 4);
         DMF_CM(1, 2);
@@ -369,14 +384,20 @@ static hipError_t launch_cm_nkc(const double* V, const unsigned short* D16, int 
 hipError_t launch_cm_i8(const double* V, const unsigned short* D16, int SD, int ND, const double* Rtp, const double* alpha,
                         const SolverState* state, int64_t N, int S, int n_c, int n_u, double* cm, hipStream_t st) {
     if (!cm_i8_supported(V, S, n_c, n_u, ND, SD) || cm == nullptr || D16 == nullptr) return hipErrorInvalidValue;
-    switch ((n_c + 3) / 4) {
-        case 0: return launch_cm_nkc<0>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
-        case 1: return launch_cm_nkc<1>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
-        case 2: return launch_cm_nkc<2>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
-        case 3: return launch_cm_nkc<3>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
-        case 4: return launch_cm_nkc<4>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, st);
-        default: return hipErrorInvalidValue;
+    for (int col0 = 0; col0 < S; col0 += kCmPanel) {  // panels of 256 samples; the second and later ones add to cm
+        const int Sp = S - col0 < kCmPanel ? S - col0 : kCmPanel;
+        hipError_t e;
+        switch ((n_c + 3) / 4) {
+            case 0: e = launch_cm_nkc<0>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
+            case 1: e = launch_cm_nkc<1>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
+            case 2: e = launch_cm_nkc<2>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
+            case 3: e = launch_cm_nkc<3>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
+            case 4: e = launch_cm_nkc<4>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
+            default: return hipErrorInvalidValue;
+        }
+        if (e != hipSuccess) return e;
     }
+    return hipSuccess;
 }
 
 }  // namespace dmf

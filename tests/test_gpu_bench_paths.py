@@ -244,14 +244,18 @@ def test_in_launch_hand_overs_are_race_free(ctx, N, S, n_c, n_u, depth):
     (2100, 512, 12, 4, 40, ["rowpass=k_rowpass_v2<3,4>", "nw=8", "gram=k_gram_i8<nd=1>"]),
     (1500, 449, 0, 1, 40, ["rowpass=k_rowpass_v2<0,1>", "nw=8"]),
     (1234, 384, 16, 3, 2500, ["rowpass=k_rowpass_v2<4,3>", "nw=6", "gram=k_gram_i8<nd=2>"]),
-    (2500, 512, 10, 5, 40, ["rowpass=k_u_phase_mfma", "gram=k_bu_cols+k_gram_i8<nd=1>"]),
-    (1700, 321, 10, 5, 40, ["rowpass=k_u_phase_mfma", "gram=k_bu_cols+k_gram_i8<nd=1>"]),  # odd S in k_bu_cols2 / k_cost_cols2
-    (1800, 640, 6, 2, 40, ["rowpass=k_u_phase_gram"]),  # beyond 512 samples: the any-shape kernels
+    # wider row groups, or more than 512 samples: the producer of the wide-row-group path walks panels of 256 samples
+    (2500, 512, 10, 5, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_bu_cols+k_gram_i8<nd=1>"]),
+    (1700, 321, 10, 5, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_bu_cols+k_gram_i8<nd=1>"]),  # odd S, 65-sample panel
+    (1800, 640, 6, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows"]),      # narrow row group beyond the row pass's 512 samples
+    (1100, 1024, 12, 4, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_bu_cols+k_gram_i8<nd=1>"]),  # four full panels
+    (900, 769, 0, 9, 2500, ["rowpass=k_cm_i8<nd=2>+k_u_inner_rows"]),     # a one-sample fourth panel, two count digit planes
+    (700, 1030, 3, 2, 40, ["rowpass=k_u_phase_gram"]),                    # beyond 1024 samples: the any-shape kernels
 ])
 def test_beyond_256_samples(ctx, N, S, n_c, n_u, depth, expect):
     """257..512 samples with up to four unknowns: the second-generation row pass as ONE workgroup of up to eight waves per
-    CU.  Wider row groups or more samples: the u phase on the first-generation MFMA kernels, with the integer Gram (b_u
-    stream kernel) and the u16 cost kernel behind them."""
+    CU.  Wider row groups or up to 1024 samples: k_cm_i8 over panels of 256 samples + the inner-iteration kernel, with the
+    integer Gram (b_u stream kernel) and the u16 cost kernel behind them."""
     from demethify_amd import _lib as L
 
     V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=11, depth=depth)
