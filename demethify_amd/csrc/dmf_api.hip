@@ -78,7 +78,7 @@ struct dmf_problem {
     double* consts = nullptr;    // device {dsq, ||Rt||^2, dmax, max |D - f32(D)|, int-count max or inf, Rt outside [0,1]}
     double h_consts[6] = {0, 0, 0, 0, 0, 0};
     // integer copies of the counts for the second-generation kernels (dmf_kernels_rowpass2.hip, dmf_kernels_gram_i8.hip):
-    // built when every count is an integer in [0, 32639], S <= 1024 and R_trunc lies in [0, 1]
+    // built when every count is an integer in [0, 32639], S <= 2048 and R_trunc lies in [0, 1]
     unsigned short* D16 = nullptr;  // [N16][SD], zero padded
     signed char* Dt8 = nullptr;     // [ND][ceil(N / 32)][SD / 32][32][32] balanced 8-bit digits, MFMA B layout
     int ND = 0;                     // count digits: 0 = no integer copies, 1 (d <= 127), 2 (d <= 32639)
@@ -298,9 +298,9 @@ int problem_finalize(dmf_problem* p, bool counts_done = false) {
     if (!std::isfinite(p->h_consts[2]) || !std::isfinite(p->h_consts[1])) return DMF_ERR_NONFINITE;
 
     // integer copies of the counts (u16 row-major for the row pass, 8-bit digit planes for the integer-MFMA Gram)
-    // (S <= 1024: the row pass itself stops at 256 samples, the integer Gram, b_u and cost kernels do not)
+    // (S <= 2048: the row pass itself stops at 512 samples; the panel producer, the integer Gram, b_u and cost kernels do not)
     if (!counts_done && ctx->generic_level == 0 && p->h_consts[4] <= 32639.0 && p->h_consts[5] == 0.0 && S >= 2 &&
-        S <= 1024 && n_c <= 16) {
+        S <= 2048 && n_c <= 16) {
         p->ND = p->h_consts[4] <= 127.0 ? 1 : 2;
         p->SD = (int)((S + 63) / 64 * 64);
         p->N16 = (N + 15) / 16 * 16;

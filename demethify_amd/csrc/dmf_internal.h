@@ -157,7 +157,7 @@ hipError_t launch_u_phase_split(const double* V, const double* D, const unsigned
                                 const double* alpha, double* u, double* u_prev, const SolverState* state, int64_t N, int S,
                                 int n_c, int n_u, int n_iter2, int mode, double* cm, double* beta, hipStream_t st);
 
-// split u phase whose producer runs M_i on the integer matrix cores (dmf_kernels_cm_i8.hip): n_u <= 16, 2 <= S <= 1024
+// split u phase whose producer runs M_i on the integer matrix cores (dmf_kernels_cm_i8.hip): n_u <= 16, 2 <= S <= 2048
 // (panels of 256 samples), u16 counts with ND digit planes, alpha in [0, 1]
 bool cm_i8_supported(const double* V, int S, int n_c, int n_u, int ND, int SD);
 hipError_t launch_cm_i8(const double* V, const unsigned short* D16, int SD, int ND, const double* Rtp, const double* alpha,

@@ -328,7 +328,7 @@ constexpr int kCmPanel = 256;  // samples per launch
 
 bool cm_i8_supported(const double* V, int S, int n_c, int n_u, int ND, int SD) {
     if (n_u < 1 || n_u > 16 || n_c < 0 || n_c > 16) return false;
-    if (S < 2 || S > 1024 || (SD & 3) != 0 || SD < (S + 63) / 64 * 64) return false;
+    if (S < 2 || S > 2048 || (SD & 3) != 0 || SD < (S + 63) / 64 * 64) return false;
     if (ND != 1 && ND != 2) return false;
     if ((reinterpret_cast<uintptr_t>(V) & 7) != 0) return false;
     return cm_layout(S < kCmPanel ? S : kCmPanel, n_c, n_u).bytes <= 160 * 1024;

@@ -250,11 +250,13 @@ def test_in_launch_hand_overs_are_race_free(ctx, N, S, n_c, n_u, depth):
     (1800, 640, 6, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows"]),      # narrow row group beyond the row pass's 512 samples
     (1100, 1024, 12, 4, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_bu_cols+k_gram_i8<nd=1>"]),  # four full panels
     (900, 769, 0, 9, 2500, ["rowpass=k_cm_i8<nd=2>+k_u_inner_rows"]),     # a one-sample fourth panel, two count digit planes
-    (700, 1030, 3, 2, 40, ["rowpass=k_u_phase_gram"]),                    # beyond 1024 samples: the any-shape kernels
+    (700, 1030, 3, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows"]),      # five panels, the last one of six samples
+    (500, 2047, 12, 4, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_bu_cols+k_gram_i8<nd=1>"]),  # eight panels, odd S
+    (400, 2100, 3, 2, 40, ["rowpass=k_u_phase_gram"]),                    # beyond 2048 samples: the any-shape kernels
 ])
 def test_beyond_256_samples(ctx, N, S, n_c, n_u, depth, expect):
     """257..512 samples with up to four unknowns: the second-generation row pass as ONE workgroup of up to eight waves per
-    CU.  Wider row groups or up to 1024 samples: k_cm_i8 over panels of 256 samples + the inner-iteration kernel, with the
+    CU.  Wider row groups or up to 2048 samples: k_cm_i8 over panels of 256 samples + the inner-iteration kernel, with the
     integer Gram (b_u stream kernel) and the u16 cost kernel behind them."""
     from demethify_amd import _lib as L
 
