@@ -300,7 +300,7 @@ int problem_finalize(dmf_problem* p, bool counts_done = false) {
     // integer copies of the counts (u16 row-major for the row pass, 8-bit digit planes for the integer-MFMA Gram)
     // (S <= 2048: the row pass itself stops at 512 samples; the panel producer, the integer Gram, b_u and cost kernels do not)
     if (!counts_done && ctx->generic_level == 0 && p->h_consts[4] <= 32639.0 && p->h_consts[5] == 0.0 && S >= 2 &&
-        S <= 2048 && n_c <= 16) {
+        S <= 2048 && n_c <= 48) {
         p->ND = p->h_consts[4] <= 127.0 ? 1 : 2;
         p->SD = (int)((S + 63) / 64 * 64);
         p->N16 = (N + 15) / 16 * 16;
@@ -312,7 +312,7 @@ int problem_finalize(dmf_problem* p, bool counts_done = false) {
     }
 
     // padded copy of R_trunc for the shape-specialised kernels (aligned, branch-free row loads)
-    if (n_c > 0 && n_c <= 16) {
+    if (n_c > 0 && n_c <= 48) {  // (<= 16: every shape-specialised kernel; beyond: the wide-row-group producer, the integer Gram)
         const int nct = (int)((n_c + 3) / 4 * 4);
         if (nct == n_c) {
             p->Rtp = p->Rt;
@@ -976,8 +976,9 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     // Wide row groups (n_u 5..16) on u16 counts: the split u phase with the integer-matrix-core producer.  Measured at
     // 5e5 x 128 against what ran before: see DESIGN.md section 5.  DMF_CM_I8_MIN_NU moves the lower end (experiments).
     static const int cm_min_nu = [] { const char* v = getenv("DMF_CM_I8_MIN_NU"); return v != nullptr && atoi(v) > 0 ? atoi(v) : 5; }();
-    // (narrow row groups reach it beyond the row pass's 512 samples: the producer walks panels of 256 samples)
-    s->use_cm_i8 = ctx->generic_level == 0 && !s->use_v2 && p->ND > 0 && p->D16 != nullptr && (n_u >= cm_min_nu || S > 512) && n_u <= 16 &&
+    // (narrow row groups reach it beyond the row pass's 512 samples -- the producer walks panels of 256 samples -- and
+    // with more than 16 known types)
+    s->use_cm_i8 = ctx->generic_level == 0 && !s->use_v2 && p->ND > 0 && p->D16 != nullptr && (n_u >= cm_min_nu || S > 512 || n_c > 16) && n_u <= 16 &&
                    (n_c == 0 || (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 7) == 0)) &&
                    dmf::cm_i8_supported(p->V, (int)S, (int)n_c, (int)n_u, p->ND, p->SD);
     // shapes the second-generation row pass does not take (n_u 5..20, long inner loops): the u phase stays a kernel of its
@@ -1258,7 +1259,7 @@ int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t
     const bool tps = s->ctx->generic_level == 1 || s->ctx->generic_level == 2;
     const char* alpha = s->purity != nullptr ? (K <= 16 && n_c >= 1 ? "k_alpha_frank_wolfe_row16" : "k_alpha_frank_wolfe")
                         : (!tps && K <= 16)  ? "k_alpha_phase_row16"
-                        : (!tps && K <= 32)  ? "k_alpha_phase_lanes"
+                        : (!tps && K <= 64)  ? "k_alpha_phase_lanes"
                         : (tps && K <= 16)   ? "k_alpha_phase"
                                              : "k_alpha_phase_dyn";
     snprintf(buf, (size_t)cap, "rowpass=%s gram=%s alpha=%s", row, gram, alpha);

@@ -34,10 +34,11 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int kCmWaves = 8;  // waves per workgroup (they only share the LDS tables)
+constexpr int kCmNkcWide = 12;  // chain links of the instantiation for more than 16 known types (n_c <= 48)
 
 struct CmLayout {
     int AS;          // row stride of the alpha copy in doubles (64 ncg + 4)
-    int n_rows;      // 4 NKC (negated known rows, zero padded) + n_u
+    int n_rows;      // 4 ceil(n_c / 4) (negated known rows, zero padded) + n_u
     int pd_dwords4;  // P digit table: [ncg][nmt][7][64] x 16 bytes
     size_t bytes;
 };
@@ -68,6 +69,11 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
     constexpr int NWT = 7 + ND - 1;  // digit weights 256^0 .. 256^(NWT-1)
     const int NP = n_u * (n_u + 1) / 2, NV = n_u + NP;
     const int nmt = (NP + 15) / 16, ncg = (Sp + 63) / 64;
+    // NKC <= 4: exactly ceil(n_c / 4) chain links.  NKC = kCmNkcWide: up to that many (more than 16 known types), the
+    // links behind wave-uniform guards, and the block's R_trunc rows fetched at the block (not a block ahead: registers).
+    const int nkc = NKC <= 4 ? NKC : (n_c + 3) / 4;
+    const int nct = 4 * nkc;
+    constexpr bool kRtAhead = NKC <= 4;
     const CmLayout L = cm_layout(Sp, n_c, n_u);
     v4i* __restrict__ pd = reinterpret_cast<v4i*>(lds_raw);
     double* __restrict__ alds = reinterpret_cast<double*>(lds_raw + (size_t)L.pd_dwords4 * 16);
@@ -83,8 +89,8 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
         const int r = i / AS, c = i - r * AS;
         double val = 0.0;
         if (c < Sp) {
-            if (r < 4 * NKC) val = r < n_c ? -alpha[(int64_t)r * S + col0 + c] : 0.0;
-            else val = alpha[(int64_t)(n_c + r - 4 * NKC) * S + col0 + c];
+            if (r < nct) val = r < n_c ? -alpha[(int64_t)r * S + col0 + c] : 0.0;
+            else val = alpha[(int64_t)(n_c + r - nct) * S + col0 + c];
         }
         alds[i] = val;
     }
@@ -168,19 +174,21 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
 
     v4d nv[4];
     unsigned long long nd[4];
-    double nrt[2][NKC > 0 ? NKC : 1];
+    double nrt[2][kRtAhead && NKC > 0 ? NKC : 1];
     {
         const int64_t r0 = row_of(blk, 0), r1 = row_of(blk, 1);
 #pragma unroll
         for (int t = 0; t < 4; ++t) load_strip(r0, 0, t, nv[t], nd[t]);
+        if constexpr (kRtAhead) {
 #pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) {
-            nrt[0][kc] = Rtp[r0 * (4 * NKC) + kc * 4 + q];
-            nrt[1][kc] = Rtp[r1 * (4 * NKC) + kc * 4 + q];
+            for (int kc = 0; kc < NKC; ++kc) {
+                nrt[0][kc] = Rtp[r0 * nct + kc * 4 + q];
+                nrt[1][kc] = Rtp[r1 * nct + kc * 4 + q];
+            }
         }
     }
     const int m16c = m16 < n_u ? m16 : 0;  // (rows >= n_u of the c tile are never stored: any finite operand will do)
-    const double* __restrict__ a2row = alds + (4 * NKC + m16c) * AS + 4 * q;
+    const double* __restrict__ a2row = alds + (nct + m16c) * AS + 4 * q;
     const double* __restrict__ a1row = alds + q * AS + 4 * (m16 & 3) + (m16 >> 2);  // + 4 kc AS + 64 cg + 16 t
 
     for (; blk < nblk; blk += stride) {
@@ -188,17 +196,26 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
         const int64_t rowh[2] = {row_of(blk, 0), row_of(blk, 1)};
         const int64_t rown0 = row_of(nxt, 0);
         double rtop[2][NKC > 0 ? NKC : 1];
-#pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) {
-            rtop[0][kc] = nrt[0][kc];
-            rtop[1][kc] = nrt[1][kc];
-        }
-        if (NKC > 0) {
-            const int64_t rown1 = row_of(nxt, 1);
+        if constexpr (kRtAhead) {
 #pragma unroll
             for (int kc = 0; kc < NKC; ++kc) {
-                nrt[0][kc] = Rtp[rown0 * (4 * NKC) + kc * 4 + q];
-                nrt[1][kc] = Rtp[rown1 * (4 * NKC) + kc * 4 + q];
+                rtop[0][kc] = nrt[0][kc];
+                rtop[1][kc] = nrt[1][kc];
+            }
+            if (NKC > 0) {
+                const int64_t rown1 = row_of(nxt, 1);
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc) {
+                    nrt[0][kc] = Rtp[rown0 * nct + kc * 4 + q];
+                    nrt[1][kc] = Rtp[rown1 * nct + kc * 4 + q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) {
+                const int kk = kc < nkc ? kc : 0;  // (links past ceil(n_c / 4) are skipped below)
+                rtop[0][kc] = Rtp[rowh[0] * nct + kk * 4 + q];
+                rtop[1][kc] = Rtp[rowh[1] * nct + kk * 4 + q];
             }
         }
         v4d cacc[2] = {v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}};
@@ -230,8 +247,10 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
                         __builtin_amdgcn_sched_barrier(0);        // ... in front of this strip's MFMAs
 #pragma unroll
                         for (int kc = 0; kc < NKC; ++kc) {
-                            const double a1 = a1row[4 * kc * AS + 64 * cg + 16 * t];
-                            e = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, rtop[h][kc], e, 0, 0, 0);
+                            if (NKC <= 4 || kc < nkc) {  // (wave-uniform)
+                                const double a1 = a1row[4 * kc * AS + 64 * cg + 16 * t];
+                                e = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, rtop[h][kc], e, 0, 0, 0);
+                            }
                         }
                         const unsigned int dl = (unsigned int)dd, dh = (unsigned int)(dd >> 32);
                         const v4d d = {(double)(dl & 0xFFFFu), (double)(dl >> 16), (double)(dh & 0xFFFFu), (double)(dh >> 16)};
@@ -327,7 +346,7 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
 constexpr int kCmPanel = 256;  // samples per launch
 
 bool cm_i8_supported(const double* V, int S, int n_c, int n_u, int ND, int SD) {
-    if (n_u < 1 || n_u > 16 || n_c < 0 || n_c > 16) return false;
+    if (n_u < 1 || n_u > 16 || n_c < 0 || n_c > 4 * kCmNkcWide) return false;
     if (S < 2 || S > 2048 || (SD & 3) != 0 || SD < (S + 63) / 64 * 64) return false;
     if (ND != 1 && ND != 2) return false;
     if ((reinterpret_cast<uintptr_t>(V) & 7) != 0) return false;
@@ -393,7 +412,7 @@ hipError_t launch_cm_i8(const double* V, const unsigned short* D16, int SD, int 
             case 2: e = launch_cm_nkc<2>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
             case 3: e = launch_cm_nkc<3>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
             case 4: e = launch_cm_nkc<4>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
-            default: return hipErrorInvalidValue;
+            default: e = launch_cm_nkc<kCmNkcWide>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
         }
         if (e != hipSuccess) return e;
     }

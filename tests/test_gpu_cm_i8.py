@@ -195,3 +195,28 @@ def test_resampled_problem_with_odd_sample_count(ctx, S, n_c, n_u):
         s.step(T1, 20, 0.0)
         u, alpha, _, _ = s.get()
     assert np.abs(alpha - wa).max() < TIGHT and np.abs(u - wu).max() < TIGHT
+
+
+# more than 16 known cell types (reference atlases): the producer's chain of up to 12 links behind wave-uniform guards, the
+# integer Gram while a row's known + unknown values fit 32 doubles, a wave per sample in the alpha phase beyond K = 32
+MANY_KNOWN_CASES = [
+    (1500, 128, 25, 3, 3, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_bu_cols+k_gram_i8<nd=1>", "alpha=k_alpha_phase_lanes"], "K = 28"),
+    (1200, 64, 28, 4, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_bu_cols+k_gram_i8<nd=1>"], "row image of exactly 32 doubles, 122 features"),
+    (800, 130, 17, 6, 2, 2500, ["rowpass=k_cm_i8<nd=2>+k_inner_bu", "gram=k_gram_i8<nd=2>"], "17 known types: five chain links, one column of the padded copy in use"),
+    (900, 200, 39, 2, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_gram_mfma", "alpha=k_alpha_phase_lanes"], "K = 41: a wave per sample in the alpha phase"),
+    (700, 96, 48, 2, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "alpha=k_alpha_phase_lanes"], "48 known types: all twelve chain links"),
+    (600, 300, 20, 8, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows"], "two panels, wide row group, 20 known types"),
+]
+
+
+@pytest.mark.parametrize("N,S,n_c,n_u,T1,depth,expect,why", MANY_KNOWN_CASES)
+def test_many_known_types_against_oracle(ctx, N, S, n_c, n_u, T1, depth, expect, why):
+    from demethify_amd import _lib as L
+
+    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=43, depth=depth)
+    u0, a0, wu, wa = _oracle(V, D, Rt, n_c, n_u, T1, seed=9)
+    u, alpha, cost, direct, _ = _solve_at_level(ctx, 0, V, D, Rt, u0, a0, L.DMF_MODE_PARTIAL, T1, expect)
+    assert rel_err(alpha, wa) < TIGHT and np.abs(alpha - wa).max() < TIGHT, why
+    assert np.abs(u - wu).max() < TIGHT, why
+    want = osol.weighted_cost(V, np.c_[Rt, wu], wa, D)
+    assert cost == pytest.approx(want, rel=1e-9) and direct == pytest.approx(want, rel=1e-11)
