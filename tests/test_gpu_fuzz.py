@@ -25,3 +25,11 @@ def test_random_wide_row_groups_against_oracle():
                           capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0 and "MISMATCH" not in proc.stdout, (proc.stdout[-3000:], proc.stderr[-2000:])
     assert "70 cases" in proc.stdout and "k_cm_i8" in proc.stdout
+
+
+def test_random_many_known_types_against_oracle():
+    """... and towards 17..48 known cell types (the producer's long chain, a wave per sample in the alpha phase)."""
+    proc = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz_parity.py"), "50", "3", "many"], cwd=ROOT,
+                          capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0 and "MISMATCH" not in proc.stdout, (proc.stdout[-3000:], proc.stderr[-2000:])
+    assert "50 cases" in proc.stdout and "k_cm_i8" in proc.stdout

@@ -1,6 +1,6 @@
 """Randomised differential run: the device solver against the CPU oracle on random small shapes (kernel selection level 0),
 including ragged sample counts, partial last blocks, zero-coverage cells, one and two count digits, wide and narrow
-reference blocks.   python tools/fuzz_parity.py [cases] [seed] [wide]"""
+reference blocks.   python tools/fuzz_parity.py [cases] [seed] [wide|many]"""
 import sys
 import time
 from pathlib import Path
@@ -14,16 +14,20 @@ from demethify_amd.device import Context, Problem, Solver
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-wide = len(sys.argv) > 3 and sys.argv[3] == "wide"  # bias towards 5..16 unknowns on shapes k_cm_i8 / k_inner_bu take
+many = len(sys.argv) > 3 and sys.argv[3] == "many"  # bias towards 17..48 known types
+wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "many")  # bias towards 5..16 unknowns on shapes k_cm_i8 / k_inner_bu take
 ctx = Context(0)
 worst, t0, paths = 0.0, time.time(), {}
 for case in range(n_cases):
     N = int(rng.choice([rng.randint(1, 40), rng.randint(40, 600), rng.randint(600, 6000)]))
     S = int(rng.choice([2 * rng.randint(1, 129), rng.randint(1, 300), 64, 128, 256]))
     n_c = int(rng.choice([0, rng.randint(1, 17)]))
+    if many and rng.rand() < 0.7:
+        n_c = int(rng.randint(17, 49))  # reference atlases: more than 16 known types
     n_u = int(rng.randint(1, 17)) if (wide and rng.rand() < 0.7) else int(rng.randint(1, 9 if n_c else 13))
     if wide and rng.rand() < 0.6:
         S = 4 * int(rng.randint(1, 65))  # the wide-row-group producer takes S % 4 == 0, S <= 256
+    n_u = min(n_u, 64 - n_c)
     depth = int(rng.choice([5, 40, 120, 900, 20000]))
     T1 = int(rng.randint(1, 4))
     V, D, Rt = osol.synthetic_problem(N, S, max(n_c, 1), n_u, seed=int(rng.randint(1 << 30)), depth=depth)
