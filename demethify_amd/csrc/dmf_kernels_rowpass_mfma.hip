@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256 * NSG) void k_inner_bu(const double* __restrict
 }
 
 bool u_inner_bu_supported(const double* V, int S, int SD, int n_u, int n_iter2) {
-    return n_u >= 5 && n_u <= 16 && S >= 2 && S <= 256 && (SD & 1) == 0 && n_iter2 <= kInnerBuMaxSteps &&
+    return n_u >= 1 && n_u <= 16 && S >= 2 && S <= 256 && (SD & 1) == 0 && n_iter2 <= kInnerBuMaxSteps &&
            (reinterpret_cast<uintptr_t>(V) & 7) == 0;
 }
 
@@ -709,6 +709,7 @@ static hipError_t launch_u_inner_bu(const double* cm, double* beta, double* u, d
         }                                                 \
         break;
     switch (n_u) {
+        DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4)  // (narrow row groups behind the producer: more than 16 known types)
         DMF_CASE(5) DMF_CASE(6) DMF_CASE(7) DMF_CASE(8) DMF_CASE(9) DMF_CASE(10) DMF_CASE(11) DMF_CASE(12) DMF_CASE(13)
         DMF_CASE(14) DMF_CASE(15) DMF_CASE(16)
         default: return hipErrorInvalidValue;

@@ -200,8 +200,8 @@ def test_resampled_problem_with_odd_sample_count(ctx, S, n_c, n_u):
 # more than 16 known cell types (reference atlases): the producer's chain of up to 12 links behind wave-uniform guards, the
 # integer Gram while a row's known + unknown values fit 32 doubles, a wave per sample in the alpha phase beyond K = 32
 MANY_KNOWN_CASES = [
-    (1500, 128, 25, 3, 3, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_bu_cols+k_gram_i8<nd=1>", "alpha=k_alpha_phase_lanes"], "K = 28"),
-    (1200, 64, 28, 4, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_bu_cols+k_gram_i8<nd=1>"], "row image of exactly 32 doubles, 122 features"),
+    (1500, 128, 25, 3, 3, 40, ["rowpass=k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>", "alpha=k_alpha_phase_lanes"], "K = 28"),
+    (1200, 64, 28, 4, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "row image of exactly 32 doubles, 122 features"),
     (800, 130, 17, 6, 2, 2500, ["rowpass=k_cm_i8<nd=2>+k_inner_bu", "gram=k_gram_i8<nd=2>"], "17 known types: five chain links, one column of the padded copy in use"),
     (900, 200, 39, 2, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_gram_mfma", "alpha=k_alpha_phase_lanes"], "K = 41: a wave per sample in the alpha phase"),
     (700, 96, 48, 2, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "alpha=k_alpha_phase_lanes"], "48 known types: all twelve chain links"),
