@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_cost_cols(const double* __restrict__ V,
 // and one 4-byte load of the counts per row and lane instead of 8 + 2 bytes -- half the load instructions per byte.
 // The headline shape streams 2.56 GB per evaluation; the one-sample form reached 3.9 TB/s, 62 % of what a plain copy
 // gets on this part.  Per-element arithmetic as above; a lane's two samples have an accumulator each.
-template <int NKC, int NU>
+template <int NKC, int NU, bool ODD>
 __global__ __launch_bounds__(256) void k_cost_cols2(const double* __restrict__ V, const unsigned short* __restrict__ Dh, int SD,
                                                     const double* __restrict__ Rtp, const double* __restrict__ u,
                                                     const double* __restrict__ alpha, int64_t N, int S, int n_c,
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_cost_cols2(const double* __restrict__ V
     // odd S: the row's last sample sits alone in its lane -- it takes the upper half of the pair one element lower (never
     // past the end of a row), its partner's count is the zero padding of the u16 copy; rows of V then start 8 bytes off a
     // 16-byte boundary every other time, which 16-byte loads take (tools/align_probe.hip)
-    const bool lone = s == S - 1;
+    const bool lone = ODD && s == S - 1;  // (ODD: S is odd -- the even form carries none of this)
     const int sc = lone ? S - 2 : (active ? s : 0);  // V / alpha column of the pair fetched
     const int sd = active ? s : 0;                   // count pair (4-byte aligned: s is even)
     typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
@@ -420,8 +420,12 @@ static hipError_t launch_cost_cols_t(const double* V, const double* D, const uns
         const int ny2 = (S + 127) / 128;
         nbx = (int)(want < 1 ? 1 : want);
         if (nbx > 1024 / ny2) nbx = 1024 / ny2;
-        hipLaunchKernelGGL((k_cost_cols2<NKC, NU>), dim3(nbx, ny2), dim3(256), 0, st, V, D16, SD, Rtp, u, alpha, N, S, n_c,
-                           scratch);
+        if (S & 1)
+            hipLaunchKernelGGL((k_cost_cols2<NKC, NU, true>), dim3(nbx, ny2), dim3(256), 0, st, V, D16, SD, Rtp, u, alpha, N, S,
+                               n_c, scratch);
+        else
+            hipLaunchKernelGGL((k_cost_cols2<NKC, NU, false>), dim3(nbx, ny2), dim3(256), 0, st, V, D16, SD, Rtp, u, alpha, N, S,
+                               n_c, scratch);
         hipLaunchKernelGGL(k_reduce_final<1>, dim3(1), dim3(256), 0, st, scratch, nbx * ny2, out, (const int*)nullptr);
         return hipGetLastError();
     }
@@ -476,7 +480,12 @@ static hipError_t launch_cost_cols2_wide_t(const double* V, const unsigned short
     const int64_t want = (N + 4 * 8 - 1) / (4 * 8);
     int nbx = (int)(want < 1 ? 1 : want);
     if (nbx > 1024 / ny2) nbx = 1024 / ny2;  // scratch: 1024 partials
-    hipLaunchKernelGGL((k_cost_cols2<NKC, NU>), dim3(nbx, ny2), dim3(256), 0, st, V, D16, SD, Rtp, u, alpha, N, S, n_c, scratch);
+    if (S & 1)
+        hipLaunchKernelGGL((k_cost_cols2<NKC, NU, true>), dim3(nbx, ny2), dim3(256), 0, st, V, D16, SD, Rtp, u, alpha, N, S, n_c,
+                           scratch);
+    else
+        hipLaunchKernelGGL((k_cost_cols2<NKC, NU, false>), dim3(nbx, ny2), dim3(256), 0, st, V, D16, SD, Rtp, u, alpha, N, S, n_c,
+                           scratch);
     hipLaunchKernelGGL(k_reduce_final<1>, dim3(1), dim3(256), 0, st, scratch, nbx * ny2, out, (const int*)nullptr);
     return hipGetLastError();
 }
