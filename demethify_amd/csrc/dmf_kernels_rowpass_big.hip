@@ -96,7 +96,7 @@ __global__ __launch_bounds__(GS == 16 ? 256 : 512) void k_u_phase_big(
     int out_base[kBigTilesPerWave];
 #pragma unroll
     for (int x = 0; x < kBigTilesPerWave; ++x) {
-        const int tile = wave * kBigTilesPerWave + x;
+        const int tile = x * NWV + wave;  // round robin: 12 tiles over 8 waves are 2,2,2,2,1,1,1,1, not 3,3,3,3,0,0,0,0
         is_c[x] = tile < CT;
         live[x] = false;
         row_a[x] = row_b[x] = 0;
