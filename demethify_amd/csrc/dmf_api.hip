@@ -978,7 +978,7 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     static const int cm_min_nu = [] { const char* v = getenv("DMF_CM_I8_MIN_NU"); return v != nullptr && atoi(v) > 0 ? atoi(v) : 5; }();
     // (narrow row groups reach it beyond the row pass's 512 samples -- the producer walks panels of 256 samples -- and
     // with more than 16 known types)
-    s->use_cm_i8 = ctx->generic_level == 0 && !s->use_v2 && p->ND > 0 && p->D16 != nullptr && (n_u >= cm_min_nu || S > 512 || n_c > 16) && n_u <= 16 &&
+    s->use_cm_i8 = ctx->generic_level == 0 && !s->use_v2 && p->ND > 0 && p->D16 != nullptr && (n_u >= cm_min_nu || S > 512 || n_c > 16) && n_u <= 32 &&
                    (n_c == 0 || (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 7) == 0)) &&
                    dmf::cm_i8_supported(p->V, (int)S, (int)n_c, (int)n_u, p->ND, p->SD);
     // shapes the second-generation row pass does not take (n_u 5..20, long inner loops): the u phase stays a kernel of its

@@ -43,9 +43,10 @@ struct CmLayout {
     size_t bytes;
 };
 
-__host__ __device__ inline CmLayout cm_layout(int S, int n_c, int n_u) {
+// (n_tiles: 16-pair tiles of M_i held by one launch; <= 0: all of them)
+__host__ __device__ inline CmLayout cm_layout(int S, int n_c, int n_u, int n_tiles = 0) {
     CmLayout L;
-    const int ncg = (S + 63) / 64, nmt = (n_u * (n_u + 1) / 2 + 15) / 16;
+    const int ncg = (S + 63) / 64, nmt = n_tiles > 0 ? n_tiles : (n_u * (n_u + 1) / 2 + 15) / 16;
     L.AS = 64 * ncg + 4;
     L.n_rows = (n_c + 3) / 4 * 4 + n_u;
     L.pd_dwords4 = ncg * nmt * 7 * 64;
@@ -60,7 +61,10 @@ template <int NKC, int ND, int NCGX, bool S4>
 __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, const unsigned short* __restrict__ D16, int SD,
                                                const double* __restrict__ Rtp, const double* __restrict__ alpha,
                                                const SolverState* __restrict__ state, int64_t N, int S, int n_c, int n_u,
-                                               double* __restrict__ cm_out, int col0, int Sp, int accumulate) {
+                                               double* __restrict__ cm_out, int col0, int Sp, int accumulate, int c_tile,
+                                               int c_store, int mt0, int mt1) {
+    // More than 16 unknowns: a launch computes ONE 16-row tile of c (unknowns 16 c_tile ..; stored if c_store) and the
+    // pair tiles mt0 .. mt1 - 1 of M_i -- the digit table of all of them (21 tiles at 25 unknowns) does not fit the LDS.
     // A launch covers the PANEL of samples col0 .. col0 + Sp - 1 (Sp <= 256) of rows that are S samples long; beyond 256
     // samples the launcher walks the panels and every launch but the first adds to what is in cm_out (a wave owns its
     // rows, the panels follow each other on the stream: fixed summation order).
@@ -68,13 +72,14 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
     if (state->done) return;
     constexpr int NWT = 7 + ND - 1;  // digit weights 256^0 .. 256^(NWT-1)
     const int NP = n_u * (n_u + 1) / 2, NV = n_u + NP;
-    const int nmt = (NP + 15) / 16, ncg = (Sp + 63) / 64;
+    const int ncg = (Sp + 63) / 64;
     // NKC <= 4: exactly ceil(n_c / 4) chain links.  NKC = kCmNkcWide: up to that many (more than 16 known types), the
     // links behind wave-uniform guards, and the block's R_trunc rows fetched at the block (not a block ahead: registers).
     const int nkc = NKC <= 4 ? NKC : (n_c + 3) / 4;
     const int nct = 4 * nkc;
     constexpr bool kRtAhead = NKC <= 4;
-    const CmLayout L = cm_layout(Sp, n_c, n_u);
+    const int ntl = mt1 - mt0;  // pair tiles of this launch
+    const CmLayout L = cm_layout(Sp, n_c, n_u, ntl);
     v4i* __restrict__ pd = reinterpret_cast<v4i*>(lds_raw);
     double* __restrict__ alds = reinterpret_cast<double*>(lds_raw + (size_t)L.pd_dwords4 * 16);
     const int AS = L.AS;
@@ -96,8 +101,8 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
     }
     // P digits: item (column group, pair tile) per wave; lane (pair m16, q), register g = strip, byte i:
     // sample 64 cg + 16 g + 4 q + i  (the k order in which the row loop packs the counts)
-    for (int item = wave; item < ncg * nmt; item += kCmWaves) {
-        const int cg = item / nmt, mt = item - cg * nmt;
+    for (int item = wave; item < ncg * ntl; item += kCmWaves) {
+        const int cg = item / ntl, mt = mt0 + (item - cg * ntl);
         const int p = mt * 16 + m16;
         int pl = 0;
         while ((pl + 1) * (pl + 2) / 2 <= p) ++pl;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
             }
         }
     }
-    const int m16c = m16 < n_u ? m16 : 0;  // (rows >= n_u of the c tile are never stored: any finite operand will do)
+    const int m16c = 16 * c_tile + m16 < n_u ? 16 * c_tile + m16 : 0;  // (rows >= n_u of the c tile are never stored: any finite operand will do)
     const double* __restrict__ a2row = alds + (nct + m16c) * AS + 4 * q;
     const double* __restrict__ a1row = alds + q * AS + 4 * (m16 & 3) + (m16 >> 2);  // + 4 kc AS + 64 cg + 16 t
 
@@ -282,11 +287,13 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
             const int64_t row = row00 + 16 * h + m16;
             if (row < N) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (q + 4 * r < n_u) {
-                        double* __restrict__ dst = cm_out + row * NV + q + 4 * r;
+                for (int r = 0; r < 4; ++r) {
+                    const int ju = 16 * c_tile + q + 4 * r;
+                    if (c_store && ju < n_u) {
+                        double* __restrict__ dst = cm_out + row * NV + ju;
                         *dst = accumulate ? *dst + cacc[h][r] : cacc[h][r];
                     }
+                }
             }
         }
 
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
         // (HJ row halves share one read of the B operand; with four column groups the count planes leave registers
         // for one half's accumulators only)
         constexpr int HJ = NCGX <= 2 ? 2 : 1;
-        for (int mt = 0; mt < nmt; ++mt) {
+        for (int mt = mt0; mt < mt1; ++mt) {
             const int p = mt * 16 + m16;
 #pragma unroll
             for (int h0 = 0; h0 < 2; h0 += HJ) {
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
 #pragma unroll
                 for (int cg = 0; cg < NCGX; ++cg) {
                     if (cg < ncg) {
-                        const v4i* __restrict__ bp = pd + ((cg * nmt + mt) * 7) * 64 + lane;
+                        const v4i* __restrict__ bp = pd + ((cg * ntl + (mt - mt0)) * 7) * 64 + lane;
 #pragma unroll
                         for (int t = 0; t < 7; ++t) {
                             const v4i b = bp[t * 64];
@@ -346,18 +353,18 @@ __global__ __launch_bounds__(512) void k_cm_i8(const double* __restrict__ V, con
 constexpr int kCmPanel = 256;  // samples per launch
 
 bool cm_i8_supported(const double* V, int S, int n_c, int n_u, int ND, int SD) {
-    if (n_u < 1 || n_u > 16 || n_c < 0 || n_c > 4 * kCmNkcWide) return false;
+    if (n_u < 1 || n_u > 32 || n_c < 0 || n_c > 4 * kCmNkcWide || n_c + n_u > 64) return false;
     if (S < 2 || S > 2048 || (SD & 3) != 0 || SD < (S + 63) / 64 * 64) return false;
     if (ND != 1 && ND != 2) return false;
     if ((reinterpret_cast<uintptr_t>(V) & 7) != 0) return false;
-    return cm_layout(S < kCmPanel ? S : kCmPanel, n_c, n_u).bytes <= 160 * 1024;
+    return cm_layout(S < kCmPanel ? S : kCmPanel, n_c, n_u, 1).bytes <= 160 * 1024;  // (at least one pair tile per launch)
 }
 
 template <int NKC, int ND, int NCGX, bool S4>
 static hipError_t launch_cm_t(const double* V, const unsigned short* D16, int SD, const double* Rtp, const double* alpha,
                               const SolverState* state, int64_t N, int S, int n_c, int n_u, double* cm, int col0, int Sp,
-                              hipStream_t st) {
-    const size_t lds = cm_layout(Sp, n_c, n_u).bytes;
+                              int c_tile, int c_store, int mt0, int mt1, hipStream_t st) {
+    const size_t lds = cm_layout(Sp, n_c, n_u, mt1 - mt0).bytes;
     static bool raised[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -375,19 +382,21 @@ static hipError_t launch_cm_t(const double* V, const unsigned short* D16, int SD
     const int64_t cap = (int64_t)256 * per_cu;
     const int64_t grid = want < cap ? want : cap;
     hipLaunchKernelGGL((k_cm_i8<NKC, ND, NCGX, S4>), dim3((unsigned)grid), dim3(kCmWaves * 64), lds, st, V, D16, SD, Rtp, alpha,
-                       state, N, S, n_c, n_u, cm, col0, Sp, col0 > 0 ? 1 : 0);
+                       state, N, S, n_c, n_u, cm, col0, Sp, col0 > 0 ? 1 : 0, c_tile, c_store, mt0, mt1);
     return hipGetLastError();
 }
 
 template <int NKC>
 static hipError_t launch_cm_nkc(const double* V, const unsigned short* D16, int SD, int ND, const double* Rtp,
                                 const double* alpha, const SolverState* state, int64_t N, int S, int n_c, int n_u,
-                                double* cm, int col0, int Sp, hipStream_t st) {
+                                double* cm, int col0, int Sp, int c_tile, int c_store, int mt0, int mt1, hipStream_t st) {
     const bool wide = Sp > 128;
     const bool s4 = (Sp & 3) == 0 && (S & 1) == 0;  // (odd S: rows of V are 8-byte aligned only)
 #define DMF_CM(ND_, NCGX_)                                                                                                  \
-    return s4 ? launch_cm_t<NKC, ND_, NCGX_, true>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st)          \
-              : launch_cm_t<NKC, ND_, NCGX_, false>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st)
+    return s4 ? launch_cm_t<NKC, ND_, NCGX_, true>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, c_tile,      \
+                                                   c_store, mt0, mt1, st)                                                   \
+              : launch_cm_t<NKC, ND_, NCGX_, false>(V, D16, SD, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, c_tile,     \
+                                                    c_store, mt0, mt1, st)
     if (ND == 1) {
         if (wide) DMF_CM(1, 4);
         DMF_CM(1, 2);
@@ -403,18 +412,31 @@ static hipError_t launch_cm_nkc(const double* V, const unsigned short* D16, int 
 hipError_t launch_cm_i8(const double* V, const unsigned short* D16, int SD, int ND, const double* Rtp, const double* alpha,
                         const SolverState* state, int64_t N, int S, int n_c, int n_u, double* cm, hipStream_t st) {
     if (!cm_i8_supported(V, S, n_c, n_u, ND, SD) || cm == nullptr || D16 == nullptr) return hipErrorInvalidValue;
+    const int nmt = (n_u * (n_u + 1) / 2 + 15) / 16, n_ct = (n_u + 15) / 16;
     for (int col0 = 0; col0 < S; col0 += kCmPanel) {  // panels of 256 samples; the second and later ones add to cm
         const int Sp = S - col0 < kCmPanel ? S - col0 : kCmPanel;
-        hipError_t e;
-        switch ((n_c + 3) / 4) {
-            case 0: e = launch_cm_nkc<0>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
-            case 1: e = launch_cm_nkc<1>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
-            case 2: e = launch_cm_nkc<2>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
-            case 3: e = launch_cm_nkc<3>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
-            case 4: e = launch_cm_nkc<4>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
-            default: e = launch_cm_nkc<kCmNkcWide>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, st); break;
+        // pair tiles per launch: what the LDS holds beside the alpha copy; at least one launch per c tile
+        int tpl = nmt;
+        while (tpl > 1 && cm_layout(Sp, n_c, n_u, tpl).bytes > (size_t)160 * 1024) --tpl;
+        int n_launch = (nmt + tpl - 1) / tpl;
+        if (n_launch < n_ct) n_launch = n_ct;
+        tpl = (nmt + n_launch - 1) / n_launch;
+        for (int li = 0; li < n_launch; ++li) {
+            const int mt0 = li * tpl < nmt ? li * tpl : nmt, mt1 = mt0 + tpl < nmt ? mt0 + tpl : nmt;
+            const int c_tile = li < n_ct ? li : n_ct - 1, c_store = li < n_ct ? 1 : 0;
+            hipError_t e;
+            switch ((n_c + 3) / 4) {
+#define DMF_NKC(X_) e = launch_cm_nkc<X_>(V, D16, SD, ND, Rtp, alpha, state, N, S, n_c, n_u, cm, col0, Sp, c_tile, c_store, mt0, mt1, st)
+                case 0: DMF_NKC(0); break;
+                case 1: DMF_NKC(1); break;
+                case 2: DMF_NKC(2); break;
+                case 3: DMF_NKC(3); break;
+                case 4: DMF_NKC(4); break;
+                default: DMF_NKC(kCmNkcWide); break;
+#undef DMF_NKC
+            }
+            if (e != hipSuccess) return e;
         }
-        if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }

@@ -510,6 +510,76 @@ __global__ __launch_bounds__(256) void k_u_inner_rows16(const double* __restrict
     }
 }
 
+// More than 16 unknowns: one CpG row per 32 lanes = two DPP rows (lane j < 16 of the first holds unknown j, of the second
+// unknown 16 + j).  Each lane keeps its own iterate value and, exchanged once per step, its partner's 16 lanes away; the
+// gradient's first 16 terms broadcast from the half that holds unknowns 0..15 (for the first DPP row that is the lane's own
+// value, for the second the partner's), the rest from the other -- row_newbcast within each DPP row, as above.
+template <int NU, int L = 0>
+__device__ __forceinline__ void grad_row32_lo(double& g, double x, const double (&Mneg)[NU]) {
+    if constexpr (L < 16) {
+        fmac_row16<L>(g, x, Mneg[L]);
+        grad_row32_lo<NU, L + 1>(g, x, Mneg);
+    }
+}
+template <int NU, int L = 16>
+__device__ __forceinline__ void grad_row32_hi(double& g, double x, const double (&Mneg)[NU]) {
+    if constexpr (L < NU) {
+        // (the first of these follows the instruction that selected x: fmac_row16<0> carries the wait states)
+        if constexpr (L == 16) fmac_row16<0>(g, x, Mneg[L]);
+        else fmac_row16<L - 16>(g, x, Mneg[L]);
+        grad_row32_hi<NU, L + 1>(g, x, Mneg);
+    }
+}
+
+template <int NU>
+__global__ __launch_bounds__(256) void k_u_inner_rows32(const double* __restrict__ cm, const double* __restrict__ beta_g,
+                                                        double* __restrict__ u, double* __restrict__ u_prev,
+                                                        const SolverState* __restrict__ state, int64_t N, int n_iter2,
+                                                        int mode) {
+    static_assert(NU > 16 && NU <= 32, "one row per two DPP rows");
+    constexpr int NP = NU * (NU + 1) / 2, NV = NU + NP;
+    extern __shared__ double beta_tab[];
+    if (state->done) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31;            // unknown of this lane
+    const bool upper = (lane & 16) != 0;  // second DPP row of the CpG row: unknowns 16..31
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 2 + (lane >> 5);
+    const bool ok = j < NU && row < N;
+    const int64_t rowc = row < N ? row : 0;
+    const int jc = j < NU ? j : 0;
+    const double inv_lw = 1.0 / state->l_w;  // as in k_u_phase_mfma
+    const double* __restrict__ mine = cm + rowc * NV;
+    const double cj = mine[jc];
+    double Mneg[NU];
+#pragma unroll
+    for (int l = 0; l < NU; ++l) Mneg[l] = j < NU ? -mine[NU + (l <= jc ? tri(l, jc) : tri(jc, l))] : 0.0;
+    const int64_t gi = rowc * NU + jc;
+    double uu = ok ? u[gi] : 0.0, up = ok ? u_prev[gi] : 0.0;
+    for (int t0 = 0; t0 < n_iter2; t0 += kBetaChunk) {
+        const int nt = n_iter2 - t0 < kBetaChunk ? n_iter2 - t0 : kBetaChunk;
+        if (t0 > 0) __syncthreads();  // the previous chunk has been consumed by every wave
+        for (int t = threadIdx.x; t < nt; t += 256) beta_tab[t] = beta_g[t0 + t];
+        __syncthreads();
+        for (int t2 = 0; t2 < nt; ++t2) {
+            const double beta = beta_tab[t2];
+            const double ut = uu + beta * (uu - up);
+            const double base = mode == 1 ? uu : ut;  // deconvolution.py:163 vs :88
+            up = uu;
+            const double other = __shfl_xor(base, 16, 64);  // the partner lane's value (lanes >= NU hold 0)
+            const double x_lo = upper ? other : base, x_hi = upper ? base : other;
+            double g = cj;
+            grad_row32_lo<NU>(g, x_lo, Mneg);
+            grad_row32_hi<NU>(g, x_hi, Mneg);
+            uu = fmin(fmax(fma(g, inv_lw, ut), 0.0), 1.0);
+            if (j >= NU) uu = 0.0;
+        }
+    }
+    if (ok) {
+        u[gi] = uu;
+        u_prev[gi] = up;
+    }
+}
+
 // The inner iterations AND b_u = u^T (D * V) of the rows just finished, in one launch (wide row groups on u16 counts; the
 // integer Gram route needs b_u from a stream over V and the counts, k_bu_cols2 as a kernel of its own).  The inner
 // iterations are a chain of dependent FP64 instructions with next to no memory traffic, the b_u stream is all memory
@@ -744,6 +814,16 @@ static hipError_t launch_u_inner(const double* cm, double* beta, double* u, doub
     switch (n_u) {
         DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4) DMF_CASE16(5) DMF_CASE16(6) DMF_CASE16(7) DMF_CASE16(8)
         DMF_CASE16(9) DMF_CASE16(10) DMF_CASE16(11) DMF_CASE16(12) DMF_CASE16(13) DMF_CASE16(14) DMF_CASE16(15) DMF_CASE16(16)
+#define DMF_CASE32(NU_)                                                                                          \
+    case NU_: {                                                                                                  \
+        const int64_t grid = (N + 7) / 8; /* 4 waves x 2 rows */                                                 \
+        hipLaunchKernelGGL((k_u_inner_rows32<NU_>), dim3((unsigned)grid), dim3(256), lds, st, cm, beta, u, u_prev, \
+                           state, N, n_iter2, mode);                                                             \
+        break;                                                                                                   \
+    }
+        DMF_CASE32(17) DMF_CASE32(18) DMF_CASE32(19) DMF_CASE32(20) DMF_CASE32(21) DMF_CASE32(22) DMF_CASE32(23) DMF_CASE32(24)
+        DMF_CASE32(25) DMF_CASE32(26) DMF_CASE32(27) DMF_CASE32(28) DMF_CASE32(29) DMF_CASE32(30) DMF_CASE32(31) DMF_CASE32(32)
+#undef DMF_CASE32
         default: return hipErrorInvalidValue;
     }
 #undef DMF_CASE

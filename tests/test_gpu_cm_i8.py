@@ -220,3 +220,30 @@ def test_many_known_types_against_oracle(ctx, N, S, n_c, n_u, T1, depth, expect,
     assert np.abs(u - wu).max() < TIGHT, why
     want = osol.weighted_cost(V, np.c_[Rt, wu], wa, D)
     assert cost == pytest.approx(want, rel=1e-9) and direct == pytest.approx(want, rel=1e-11)
+
+
+# more than 16 unknown types (upstream's --ic sweep runs to 25): two c tiles, the pair tiles of M_i over several launches of the
+# producer (their digit table does not fit the LDS at once), inner iterations with 32 lanes per CpG row
+MANY_UNKNOWN_CASES = [
+    (1500, 128, 0, 17, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows"], "17 unknowns: second c tile with one live row, 10 pair tiles in two launches"),
+    (1200, 128, 0, 20, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_bu_cols+k_gram_i8<nd=1>"], "210 pairs; integer Gram in four launches"),
+    (1000, 128, 0, 25, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_gram_mfma"], "the sweep's last candidate: 21 pair tiles in three launches"),
+    (900, 64, 6, 20, 2, 3000, ["rowpass=k_cm_i8<nd=2>+k_u_inner_rows"], "known types, two count digit planes, one column group"),
+    (800, 255, 3, 18, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows"], "odd S, four column groups"),
+    (600, 300, 0, 32, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows"], "32 unknowns (both c tiles full), two panels"),
+    (500, 40, 16, 17, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows"], "K = 33"),
+]
+
+
+@pytest.mark.parametrize("N,S,n_c,n_u,T1,depth,expect,why", MANY_UNKNOWN_CASES)
+def test_many_unknown_types_against_oracle(ctx, N, S, n_c, n_u, T1, depth, expect, why):
+    from demethify_amd import _lib as L
+
+    V, D, Rt = osol.synthetic_problem(N, S, n_c, n_u, seed=47, depth=depth)
+    u0, a0, wu, wa = _oracle(V, D, Rt, n_c, n_u, T1, seed=10)
+    mode = L.DMF_MODE_PARTIAL if n_c else L.DMF_MODE_UNSUPERVISED
+    u, alpha, cost, direct, _ = _solve_at_level(ctx, 0, V, D, Rt if n_c else None, u0, a0, mode, T1, expect)
+    assert rel_err(alpha, wa) < TIGHT and np.abs(alpha - wa).max() < TIGHT, why
+    assert np.abs(u - wu).max() < TIGHT, why
+    want = osol.weighted_cost(V, np.c_[Rt, wu] if n_c else wu, wa, D)
+    assert cost == pytest.approx(want, rel=1e-9) and direct == pytest.approx(want, rel=1e-11)

@@ -25,6 +25,8 @@ for case in range(n_cases):
     if many and rng.rand() < 0.7:
         n_c = int(rng.randint(17, 49))  # reference atlases: more than 16 known types
     n_u = int(rng.randint(1, 17)) if (wide and rng.rand() < 0.7) else int(rng.randint(1, 9 if n_c else 13))
+    if wide and rng.rand() < 0.25:
+        n_u = int(rng.randint(17, 33))  # two DPP rows per CpG row, pair tiles over several producer launches
     if wide and rng.rand() < 0.6:
         S = 4 * int(rng.randint(1, 65))  # the wide-row-group producer takes S % 4 == 0, S <= 256
     n_u = min(n_u, 64 - n_c)
