@@ -1003,7 +1003,7 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     const bool fused_bu = s->use_cm_i8 && dmf::u_inner_bu_supported(p->V, (int)S, p->SD, (int)n_u, 20);
     const bool known_ok = n_c > 0 ? (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0) : true;
     s->use_gram_i8 = ctx->generic_level == 0 && p->ND > 0 && p->D16 != nullptr && known_ok &&
-                     (fused_bu || (n_c > 0 ? fp64_acc >= i8_min_features : n_u * (n_u + 1) / 2 >= i8_min_nc0)) && n_u <= 20 &&
+                     (fused_bu || (n_c > 0 ? fp64_acc >= i8_min_features : n_u * (n_u + 1) / 2 >= i8_min_nc0)) && n_u <= 32 &&
                      dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
     if (s->use_v2 || s->use_cm_i8) {
         // the row pass writes alpha_j alpha_l in fixed point on [0, 1]: true of every iterate (columns on the simplex),

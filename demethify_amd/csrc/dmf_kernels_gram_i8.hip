@@ -37,7 +37,7 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 namespace {
 constexpr int kNSL = 7;       // balanced base-256 digits of rint(z 2^52)
 constexpr int kRing = 8;      // LDS-DMA ring: block slots
-constexpr int kMaxFeat = 256;  // (64 per launch)
+constexpr int kMaxFeat = 576;  // (64 per launch; 32 unknowns without known types: 528)
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ builders
@@ -622,6 +622,8 @@ hipError_t launch_bu_cols(const double* V, const unsigned short* D16, int SD, co
     case NU_: hipLaunchKernelGGL((k_bu_cols<NU_>), grid, block, 0, st, V, D16, SD, u, N, S, slab, done_flag); break;
         DMF_CASE(1) DMF_CASE(2) DMF_CASE(3) DMF_CASE(4) DMF_CASE(5) DMF_CASE(6) DMF_CASE(7) DMF_CASE(8) DMF_CASE(9) DMF_CASE(10)
         DMF_CASE(11) DMF_CASE(12) DMF_CASE(13) DMF_CASE(14) DMF_CASE(15) DMF_CASE(16) DMF_CASE(17) DMF_CASE(18) DMF_CASE(19) DMF_CASE(20)
+        DMF_CASE(21) DMF_CASE(22) DMF_CASE(23) DMF_CASE(24) DMF_CASE(25) DMF_CASE(26) DMF_CASE(27) DMF_CASE(28) DMF_CASE(29) DMF_CASE(30)
+        DMF_CASE(31) DMF_CASE(32)
 #undef DMF_CASE
         default: return hipErrorInvalidValue;
     }
@@ -773,7 +775,7 @@ void gram_i8_geometry(int64_t N, int SD, int* nsh, int* ny, int64_t* rows_per_wg
 bool gram_i8_supported(int n_c, int n_u, int ND, int64_t N, int SD) {
     const int nf = n_c * n_u + n_u * (n_u + 1) / 2;
     // (a block's x image -- 32 rows of the padded R_trunc copy and of u -- is fetched as at most two 4-KB pieces)
-    if ((n_c + 3) / 4 * 4 + n_u > 32 || n_u > 20 || nf < 1 || nf > kMaxFeat || ND < 1 || ND > 2) return false;
+    if ((n_c + 3) / 4 * 4 + n_u > 32 || nf < 1 || nf > kMaxFeat || ND < 1 || ND > 2) return false;
     int nsh, ny;
     int64_t rpw;
     gram_i8_geometry(N, SD, &nsh, &ny, &rpw);

@@ -64,7 +64,8 @@ WIDE_GRAM_CASES = [
     (600, 130, 3, 13, 2, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "S = 2 mod 4: the last lane of a row holds one pair in range and one out"),
     (300, 2, 2, 6, 3, 40, ["k_cm_i8<nd=1>+k_inner_bu"], "two samples"),
     (450, 6, 0, 9, 3, 900, ["k_cm_i8<nd=2>+k_inner_bu"], "six samples, two count digit planes"),
-    (700, 64, 15, 16, 2, 40, ["k_cm_i8<nd=1>+k_u_inner_rows"], "376 features: beyond the integer Gram's cap, k_gram_mfma behind k_cm_i8; K = 31"),
+    (700, 64, 15, 16, 2, 40, ["k_cm_i8<nd=1>+k_inner_bu", "gram=k_gram_i8<nd=1>"], "376 features in six launches, row image of 32 doubles; K = 31"),
+    (600, 64, 20, 14, 2, 40, ["k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_gram_mfma"], "row image of 34 doubles: beyond the integer Gram, k_gram_mfma behind k_cm_i8"),
 ]
 
 
@@ -227,7 +228,7 @@ def test_many_known_types_against_oracle(ctx, N, S, n_c, n_u, T1, depth, expect,
 MANY_UNKNOWN_CASES = [
     (1500, 128, 0, 17, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows"], "17 unknowns: second c tile with one live row, 10 pair tiles in two launches"),
     (1200, 128, 0, 20, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_bu_cols+k_gram_i8<nd=1>"], "210 pairs; integer Gram in four launches"),
-    (1000, 128, 0, 25, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_gram_mfma"], "the sweep's last candidate: 21 pair tiles in three launches"),
+    (1000, 128, 0, 25, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows", "gram=k_bu_cols+k_gram_i8<nd=1>"], "the sweep's last candidate: 21 pair tiles in three launches, 325 features in six"),
     (900, 64, 6, 20, 2, 3000, ["rowpass=k_cm_i8<nd=2>+k_u_inner_rows"], "known types, two count digit planes, one column group"),
     (800, 255, 3, 18, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows"], "odd S, four column groups"),
     (600, 300, 0, 32, 2, 40, ["rowpass=k_cm_i8<nd=1>+k_u_inner_rows"], "32 unknowns (both c tiles full), two panels"),
