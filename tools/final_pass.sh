@@ -18,3 +18,4 @@ timeout -k 10 400 python tools/ic_sweep_bench.py 50 2>&1 | grep -v amdgpu.ids > 
 timeout -k 10 300 python tools/wide_nu_sweep.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/wide_row_groups.txt
 bash tools/pmc_shape.sh final/pmc_0_8 500000 128 0 8 6 > /dev/null && python3 tools/pmc_summary.py gpurun_out/final/pmc_0_8 > gpurun_out/final/wide_pmc_0_8.txt
 bash tools/pmc_shape.sh final/pmc_0_12 500000 128 0 12 6 > /dev/null && python3 tools/pmc_summary.py gpurun_out/final/pmc_0_12 > gpurun_out/final/wide_pmc_0_12.txt
+(timeout -k 10 200 python tools/odd_s_bench.py; timeout -k 10 200 python tools/big_s_bench.py; timeout -k 10 200 python tools/big_nc_bench.py; timeout -k 10 200 python tools/big_nu_bench.py) 2>&1 | grep -v amdgpu.ids > gpurun_out/final/shape_coverage.txt
