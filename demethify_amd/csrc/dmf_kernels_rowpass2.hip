@@ -44,9 +44,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // Diagnostic build only (tools/rowpass2_probe.hip defines DMF_STAMPS): per-wave cycle sums of the kernel's segments
 // go to a debug buffer of their own; the product build compiles none of it.
 #ifdef DMF_STAMPS
-#define DMF2_STAMP_DECL unsigned long long st_last = dmf2_stamp(), st_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DMF2_STAMP_DECL unsigned long long st_last = dmf2_stamp(), st_seg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define DMF2_STAMP(i) { const unsigned long long st_now = dmf2_stamp(); st_seg[i] += st_now - st_last; st_last = st_now; }
-#define DMF2_STAMP_FLUSH if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) stamps_out[((size_t)blockIdx.x * 4 + wave) * 8 + i_] = st_seg[i_];
+#define DMF2_STAMP_FLUSH if (lane == 0) for (int i_ = 0; i_ < 16; ++i_) stamps_out[((size_t)blockIdx.x * 4 + wave) * 16 + i_] = st_seg[i_];
 __device__ __forceinline__ unsigned long long dmf2_stamp() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -54,10 +54,18 @@ __device__ __forceinline__ unsigned long long dmf2_stamp() {
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
+#define DMF2_SUB_BEGIN unsigned long long st_sub = dmf2_stamp();
+#define DMF2_SUB(i) { const unsigned long long st_now = dmf2_stamp(); st_seg[i] += st_now - st_sub; st_sub = st_now; }
 #else
 #define DMF2_STAMP_DECL
 #define DMF2_STAMP(i)
 #define DMF2_STAMP_FLUSH
+#define DMF2_SUB_BEGIN
+#define DMF2_SUB(i)
+#endif
+
+#ifndef DMF_V2_STAGGER
+#define DMF_V2_STAGGER 12  // x 64 cycles: how long the waves that do not run phase B hold back their prefetch
 #endif
 
 namespace {
@@ -72,15 +80,31 @@ constexpr int kTileBytes2 = kTileVBytes2 + kTileDBytes2 + 2 * 16 * kRowB;  // on
 // One accelerated projected-gradient step of a row group (deconvolution.py:83-88): (cur, prev) = (u, u_) in,
 // prev = the new u out (cur is then u_).  AT_PREV: gradient at the previous iterate (deconvolution.py:163) instead
 // of the extrapolated point (:88).  c and M arrive pre-scaled by 1 / l_w (M negated).
+// Ms: this lane's row of -M / l_w in ROTATED order -- Ms[r] = -M[j][(j + r) % NU] / l_w -- with the step's own "+ ut"
+// folded into Ms[0] at the extrapolated point (deconvolution.py:88; not at :163, where the gradient point differs).
+// A wave alone on its SIMD issues an FP64 instruction every 8 cycles and a 32-bit one every 4 (tools/rowpass2_probe:
+// 145 cycles per step for 11 FP64 + 10 other instructions, with or without a second workgroup on the CU), so phase B
+// costs what it issues: NU - 1 quad rotations (instead of NU broadcasts) and one FMA chain whose last link clamps --
+// 6 FP64 + 8 other instructions per step at NU = 4.
 template <int NU, bool AT_PREV>
 __device__ __forceinline__ void inner_step(double cur, double& prev, double cj, const double (&Ms)[NU], int b_lo, int b_hi,
                                            int t2, int lane0) {
     const double beta = __hiloint2double(__builtin_amdgcn_readlane(b_hi, t2), __builtin_amdgcn_readlane(b_lo, t2));
     const double ut = fma(beta, cur - prev, cur);
-    // Phase B runs alone on its SIMD's FP64 pipe most of the time and is then bound by the ~13 cycles each DEPENDENT
-    // instruction takes, so the products -M[j][l] x_l are formed independently and summed as a tree (depth 7 per step
-    // instead of 11 for one FMA chain)
-    prev = f_add_clamp01(ut + cj, f_dot_tree<NU, 0, NU>(AT_PREV ? cur : ut, Ms, lane0));
+    const double x = AT_PREV ? cur : ut;
+    if constexpr (NU == 3) {  // (three lanes per row do not tile a quad: shuffles, in the same rotated order)
+        const int jb = (threadIdx.x & 63) - lane0;
+        double acc = fma(Ms[0], x, AT_PREV ? ut + cj : cj);
+        acc = fma(Ms[1], __shfl(x, lane0 + (jb + 1) % 3, 64), acc);
+        prev = f_fma_clamp01(Ms[2], __shfl(x, lane0 + (jb + 2) % 3, 64), acc);
+    } else if constexpr (NU == 1) {
+        prev = f_fma_clamp01(Ms[0], x, AT_PREV ? ut + cj : cj);
+    } else {
+        double acc = fma(Ms[0], x, AT_PREV ? ut + cj : cj);
+#pragma unroll
+        for (int r = 1; r < NU - 1; ++r) acc = fma(Ms[r], r == 1 ? f_group_rot<NU, 1>(x) : f_group_rot<NU, 2>(x), acc);
+        prev = f_fma_clamp01(Ms[NU - 1], NU == 2 ? f_group_rot<NU, 1>(x) : f_group_rot<NU, 3>(x), acc);
+    }
 }
 
 template <int NU, bool AT_PREV>
@@ -115,7 +139,10 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
     static_assert(NU >= 1 && NU <= 4, "one phase-B pass per block, 4x4x4 MFMA for the c product");
     constexpr int NCT = 4 * NKC;
     constexpr int NP = NU * (NU + 1) / 2;
-    constexpr int NV = NU + NP;
+    // a (row, unknown j) slot of a wave's partial sums: { c_j, M_jj, M_j(j+1), .. (round the row) } pre-scaled by 1 / l_w (M negated),
+    // padded to whole 16-byte pieces -- phase B fetches its lane's slot with SLOT / 2 ds_read_b128 per column group
+    constexpr int SLOT = (NU + 2) & ~1;
+    constexpr int NV = NU * SLOT;  // doubles per row
     extern __shared__ double lds_dyn[];
     if (state->done) return;
 
@@ -124,13 +151,14 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
     const int lane = threadIdx.x & 63;
     const int wcol0 = wave * 64;
 
-    // LDS carve-up (doubles unless noted): beta[n_iter2 (even)] | ubuf[16][NU] | red[NW][NV][16] | u2[MAXW] |
-    //   tiles[NW]{ V f64 [16][66], D f32 [16][68] }
+    // LDS carve-up (doubles unless noted): beta[n_iter2 (even)] | ubuf[16][NU] | red[MAXW][16][NU][SLOT] | u2[MAXW] |
+    //   tiles[NW]{ V f64 [16][66], D f32 [16][68], count digits [2][16][80] }
     double* __restrict__ beta_tab = lds_dyn;
     double* __restrict__ ubuf = beta_tab + ((n_iter2 + 1) & ~1);
     double* __restrict__ red = ubuf + 16 * NU;
-    double* __restrict__ u2red = red + NW * NV * 16;
-    char* __restrict__ tile = reinterpret_cast<char*>(u2red + MAXW) + (size_t)wave * kTileBytes2;
+    double* __restrict__ u2red = red + MAXW * NV * 16;
+    char* __restrict__ tile0 = reinterpret_cast<char*>(u2red + MAXW);
+    char* __restrict__ tile = tile0 + (size_t)wave * kTileBytes2;
     double* __restrict__ tileV = reinterpret_cast<double*>(tile);
     float* __restrict__ tileD = reinterpret_cast<float*>(tile + kTileVBytes2);
     char* __restrict__ tileB = tile + kTileVBytes2 + kTileDBytes2;  // [2 digit planes][16][kRowB]: counts as balanced bytes
@@ -145,6 +173,15 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
             lw_prev = lw;
         }
     }
+    // the partial-sum slots of column groups this workgroup does not have stay zero (phase B adds all MAXW of them,
+    // unrolled, so that its LDS reads go out in one batch)
+    for (int i = threadIdx.x; i < MAXW * NV * 16; i += blockDim.x) red[i] = 0.0;
+    // x / l_w as x * (1 / l_w), folded into the operands that produce c and M: <= 1 ulp from the division
+    const double inv_lw = 1.0 / state->l_w;
+    // M arrives as an exact integer multiple of 2^-52; phase B adds -M x / l_w.  (Wave-uniform: kept on the scalar side.)
+    const double m_scale_v = -inv_lw * 0x1p-52;
+    const double m_scale = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(m_scale_v)),
+                                            __builtin_amdgcn_readfirstlane(__double2loint(m_scale_v)));
 
     // ---- alpha-derived MFMA A operands of this wave's four 16-sample strips, in registers for the whole launch
     const int m16 = lane & 15, q = lane >> 4;
@@ -158,10 +195,10 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
     // P [sample][pair]).  An FP64 MFMA holds the SIMD's FP64 pipe for 64 cycles, and this product was 16 of the 28 per
     // block and wave -- time during which the other workgroup's phases B and C on the same SIMD could not issue.
     v4i pdg[7];  // B operands: digit t of P[pair = m16][samples 16 q .. 16 q + 15 of this column group]
+    int pj = 0, pl = 0;  // pair m16 = (pj <= pl)
+    while ((pl + 1) * (pl + 2) / 2 <= m16) ++pl;
+    pj = m16 - pl * (pl + 1) / 2;
     {
-        int pj = 0, pl = 0;
-        while ((pl + 1) * (pl + 2) / 2 <= m16) ++pl;
-        pj = m16 - pl * (pl + 1) / 2;
         const bool pair_ok = m16 < NP;
         const bool a2_ok = (m16 & 3) < NU;
 #pragma unroll
@@ -174,7 +211,7 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int col = k_col + 16 * t + r;
-                a2r[t][r] = (col < S && a2_ok) ? alpha[(int64_t)(n_c + (m16 & 3)) * S + col] : 0.0;
+                a2r[t][r] = (col < S && a2_ok) ? alpha[(int64_t)(n_c + (m16 & 3)) * S + col] * inv_lw : 0.0;
             }
         }
 #pragma unroll
@@ -199,11 +236,10 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
             pdg[6][g] = (int)th[2];
         }
     }
-    __syncthreads();  // beta_tab
+    __syncthreads();  // beta_tab, the zeroed slots
 
     const int64_t nblk = (N + 15) / 16;
     const int nk = (int)((nblk - blockIdx.x + gridDim.x - 1) / gridDim.x);  // blocks of this workgroup
-    const double inv_lw = 1.0 / state->l_w;  // x / l_w as x * (1 / l_w): <= 1 ulp from the division
 
     // global -> register staging: V load i covers rows 2i, 2i+1 (lane -> row half, 2 samples);
     // D16 load i covers rows 8i .. 8i+7 (lane -> row lane >> 3, 8 samples)
@@ -274,6 +310,12 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
     if (nk > 0) prefetch(blockIdx.x);
 
     double bu[4] = {0.0, 0.0, 0.0, 0.0};  // b_u[unknown q][sample 16 t + m16] of this wave's column group, t = 0..3
+    // this lane's places in its wave's partial-sum slots: c[unknown q][row m16]; M[pair m16 = (pj, pl)][rows 4 q ..] twice
+    // (M is symmetric), a slot's M entries in ROTATED order -- slot (row, j) entry r is M[j][(j + r) % NU], the order in
+    // which phase B's quad rotations deliver the iterate; rows 4 q + rr at immediate offsets
+    double* __restrict__ const mine_c = red + (size_t)wave * NV * 16 + (m16 * NU + q) * SLOT;
+    double* __restrict__ const mine_m1 = red + (size_t)wave * NV * 16 + (4 * q * NU + pl) * SLOT + 1 + (pj - pl + NU) % NU;
+    double* __restrict__ const mine_m2 = red + (size_t)wave * NV * 16 + (4 * q * NU + pj) * SLOT + 1 + (pl - pj) % NU;
     double u2_acc = 0.0;
 
     DMF2_STAMP_DECL
@@ -388,61 +430,88 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
         for (int rr = 0; rr < 4; ++rr) {
             const double lo = fma(fma(fma((double)mw[3][rr], 256.0, (double)mw[2][rr]), 256.0, (double)mw[1][rr]), 256.0, (double)mw[0][rr]);
             const double hi = fma(fma(fma((double)mw[7][rr], 256.0, (double)mw[6][rr]), 256.0, (double)mw[5][rr]), 256.0, (double)mw[4][rr]);
-            mrow[rr] = fma(hi, 0x1p32, lo) * 0x1p-52;
+            mrow[rr] = fma(hi, 0x1p32, lo) * m_scale;
         }
 #endif
         DMF2_STAMP(1)  // phase A
-        // the next block's global loads: their staging registers were free during phase A, and the loads have
-        // phases B and C (and the other workgroups' turns on this CU) to land
-        if (s + 1 < nk) prefetch(blk + gridDim.x);
+        // The next block's global loads (their staging registers were free during phase A).  A workgroup's waves reach
+        // this point together, and 42 KB of loads take the CU's one address unit ~700 cycles: only the wave that runs
+        // phase B issues its loads here; the others issue theirs behind barrier X, while they wait for phase B anyway.
         {
-            double* __restrict__ mine = red + (size_t)wave * NV * 16;
-            if (q < NU) mine[q * 16 + m16] = csm;  // c[unknown q][row m16]
-            if (m16 < NP) {  // C layout of the 16x16x64 tile: col = pair m16, rows 4 q + reg
+            if (q < NU) *mine_c = csm;  // c[unknown q][row m16]
+            if (m16 < NP) {  // C layout of the 16x16x64 tile: col = pair m16 = (pj, pl), rows 4 q + reg; M is symmetric
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) mine[(NU + m16) * 16 + 4 * q + rr] = mrow[rr];
+                for (int rr = 0; rr < 4; ++rr) mine_m1[rr * NU * SLOT] = mrow[rr];
+                if (pj != pl) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) mine_m2[rr * NU * SLOT] = mrow[rr];
+                }
             }
         }
-        DMF2_STAMP(2)  // prefetch issue + partials
-        // (a bare barrier behind an LDS-only wait: __syncthreads() would also drain vmcnt, i.e. stall every wave on
-        // the prefetch it has just issued)
+        DMF2_STAMP(2)  // partials
+        // (a bare barrier behind an LDS-only wait: __syncthreads() would also drain vmcnt)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // ---- barrier X
         DMF2_STAMP(3)  // wait X
+        // The next block's global loads (their staging registers were free during phase A).  42 KB of loads take the CU's
+        // one address unit ~700 cycles when a workgroup's waves issue them together: the wave that runs phase B goes
+        // first, the others -- who wait for phase B anyway -- a little later.  (ONE place for all waves: with the loads in
+        // two branches the register allocator gave them different destinations and put copies -- and the waits for the
+        // data -- behind one of them.)
+#ifndef DMF_V2_NO_STAGGER
+        if (!my_turn) __builtin_amdgcn_s_sleep(DMF_V2_STAGGER);
+#endif
+        if (s + 1 < nk) prefetch(blk + gridDim.x);
+        DMF2_STAMP(7)  // prefetch issue
 
         // ---- phase B: row-local inner iterations, lane = (row, unknown j); c and M pre-scaled by 1 / l_w
         if (my_turn) {
             __builtin_amdgcn_s_setprio(3);  // a dependent chain on the workgroup's critical path
+            DMF2_SUB_BEGIN
             const int lane0 = lane - jb;
             const int rlc = rl < 16 ? rl : 15;
             double cj = 0.0, Ms[NU];
 #pragma unroll
             for (int l = 0; l < NU; ++l) Ms[l] = 0.0;
-            for (int w = 0; w < NW; ++w) {
-                const double* __restrict__ part = red + (size_t)w * NV * 16;
-                cj += part[jb * 16 + rlc];
+            {
+                // this lane's slot of every column group, in column-group order (a fixed summation order); the values
+                // are already c / l_w and -M / l_w
+                const double* __restrict__ slot = red + (rlc * NU + jb) * SLOT;
+#pragma unroll 1
+                for (int w0 = 0; w0 < MAXW; w0 += 4) {  // (batches of four column groups: registers)
+                    v2d part[4][SLOT / 2];
 #pragma unroll
-                for (int l = 0; l < NU; ++l) {
-                    const int p = l <= jb ? tri(l, jb) : tri(jb, l);
-                    Ms[l] += part[(NU + p) * 16 + rlc];
+                    for (int w = 0; w < 4; ++w)
+#pragma unroll
+                        for (int h = 0; h < SLOT / 2; ++h)
+                            part[w][h] = *reinterpret_cast<const v2d*>(slot + (w0 + w) * NV * 16 + 2 * h);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        cj += part[w][0].x;
+#pragma unroll
+                        for (int l = 0; l < NU; ++l) Ms[l] += (l & 1) ? part[w][(l + 1) / 2].x : part[w][l / 2].y;
+                    }
                 }
             }
-            cj *= inv_lw;
-#pragma unroll
-            for (int l = 0; l < NU; ++l) Ms[l] *= -inv_lw;  // the chain below adds -M x
             double uu = uu0, up = up0;
+            DMF2_SUB(8)
             // The momentum coefficients ride in a VGPR (lane t holds beta_t) and reach the loop through
             // v_readlane: an LDS read here would sit on the dependent chain every step.
             for (int t0 = 0; t0 < n_iter2; t0 += 64) {
                 const int tl = t0 + lane < n_iter2 ? t0 + lane : n_iter2 - 1;
-                const double bvec = beta_tab[tl];
+                const double bvec = beta_tab[tl];  // (lane t: beta_t; the first read goes out with the partial-sum reads)
                 const int b_lo = __double2loint(bvec), b_hi = __double2hiint(bvec);
                 const int t_end = n_iter2 - t0 < 64 ? n_iter2 - t0 : 64;
                 // (u, u_) swap roles every step: written out in pairs so that no register copies sit on the chain
                 // (the loop holds v_readlane, a convergent operation the unroller will not split by itself)
-                if (mode == 1) inner_steps<NU, true>(uu, up, cj, Ms, b_lo, b_hi, t_end, lane0);
-                else inner_steps<NU, false>(uu, up, cj, Ms, b_lo, b_hi, t_end, lane0);
+                if (mode == 1) {
+                    inner_steps<NU, true>(uu, up, cj, Ms, b_lo, b_hi, t_end, lane0);
+                } else {
+                    if (t0 == 0) Ms[0] += 1.0;  // the step's own "+ ut" (deconvolution.py:88), folded into the diagonal
+                    inner_steps<NU, false>(uu, up, cj, Ms, b_lo, b_hi, t_end, lane0);
+                }
             }
+            DMF2_SUB(9)
             if (b_lane) ubuf[rl * NU + jb] = ok ? uu : 0.0;  // rows beyond N: phase C multiplies them by zero counts
             if (ok) {
                 // (buffer stores, like the loads: scalar base of the block + this lane's constant offset)
@@ -452,6 +521,7 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
                 __builtin_amdgcn_raw_buffer_store_b64(v2u{(unsigned int)__double2loint(up), (unsigned int)__double2hiint(up)}, rp, u_off, 0, 0);
                 u2_acc = fma(uu, uu, u2_acc);
             }
+            DMF2_SUB(10)
             __builtin_amdgcn_s_setprio(0);
         }
         DMF2_STAMP(4)  // phase B (or nothing)
@@ -494,6 +564,9 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
     }
 
     DMF2_STAMP_FLUSH
+    const double w2 = wave_sum(u2_acc);
+    if (lane == 0) u2red[wave] = w2;
+    __syncthreads();
     // ---- b_u slab of this workgroup [NU][S] and its share of ||u||_F^2
     if (q < NU) {
 #pragma unroll
@@ -502,9 +575,6 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
             if (sC < S) slab[((int64_t)blockIdx.x * NU + q) * S + sC] = bu[t];
         }
     }
-    const double w2 = wave_sum(u2_acc);
-    if (lane == 0) u2red[wave] = w2;
-    __syncthreads();
     if (threadIdx.x == 0) {
         double tot = 0.0;
         for (int w = 0; w < NW; ++w) tot += u2red[w];
@@ -514,8 +584,9 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
 
 size_t rowpass_v2_lds_bytes(int S, int n_u, int n_iter2) {
     const int NW = (S + 63) / 64;
-    const int nv = n_u + n_u * (n_u + 1) / 2;
-    const size_t doubles = (size_t)((n_iter2 + 1) & ~1) + 16 * n_u + (size_t)NW * nv * 16 + (NW <= 4 ? 4 : 8);
+    const int maxw = NW <= 4 ? 4 : 8;
+    const int nv = n_u * ((n_u + 2) & ~1);  // a row's partial-sum slots (k_rowpass_v2: NV)
+    const size_t doubles = (size_t)((n_iter2 + 1) & ~1) + 16 * n_u + (size_t)maxw * nv * 16 + maxw;
     return doubles * sizeof(double) + (size_t)NW * kTileBytes2;
 }
 

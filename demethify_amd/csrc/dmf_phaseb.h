@@ -57,6 +57,14 @@ __device__ __forceinline__ double f_fma_clamp01(double a, double b, double c) {
     return r;
 }
 
+// x of the lane R places further round this lane's row group (NU = 2 or 4 lanes, aligned to a quad)
+template <int NU, int R>
+__device__ __forceinline__ double f_group_rot(double x) {
+    static_assert(NU == 2 || NU == 4, "row groups that tile a quad");
+    if constexpr (NU == 2) return f_dpp_quad<1 | (0 << 2) | (3 << 4) | (2 << 6)>(x);
+    else return f_dpp_quad<((0 + R) & 3) | (((1 + R) & 3) << 2) | (((2 + R) & 3) << 4) | (((3 + R) & 3) << 6)>(x);
+}
+
 // clip(seed + sum_l x_l * Mn[l], 0, 1) over the NU lanes of a row group as one FMA chain whose last link clamps.
 // Under contention from the C waves of its SIMD the phase-B wave pays ~10 cycles per instruction issued,
 // dependent or not, so the instruction count (NU FMAs here against NU multiplies + NU adds for a balanced tree
