@@ -185,6 +185,18 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
 
     // ---- alpha-derived MFMA A operands of this wave's four 16-sample strips, in registers for the whole launch
     const int m16 = lane & 15, q = lane >> 4;
+    // Tile swizzle.  A 16-byte LDS read is served in four groups of 16 lanes that are NOT the four rows of 16 lanes
+    // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, and the same + 32): with lane = (row m16, sample piece q) a group holds
+    // rows 0-3 / 12-15 at piece q0 and rows 4-11 at piece q0 + 1 (or the other way round), and in any LINEAR layout two of
+    // those 16 lanes share a bank.  So rows 4..11 of every tile keep their 16-byte pieces pairwise swapped (a sample s of
+    // such a row sits where s ^ 4 would: V and the f32 counts; where s ^ 16 would: the byte planes) -- then each group
+    // reads 16 different rows at one piece offset, and the odd piece strides (33, 17, 5) make that conflict-free.
+    const int sw_row = (m16 >= 4 && m16 < 12) ? 1 : 0;  // is row m16 a swapped row (phase A: lane = (row, piece))
+    const int qs = q ^ sw_row;                           // where this lane's piece q sits in row m16
+    // Phase C reads with lane = (row quad member q, sample m16): rows R + 8 (q & 1) + 4 (q >> 1), R = 0..3, so that the two
+    // rows a 32-lane group of a ds_read_b64 touches lie 8 apart -- 8 x 132 dwords = 32 banks: the halves of the 64
+    const int c_row = 8 * (q & 1) + 4 * (q >> 1);
+    const int mC = m16 ^ ((q == 1 || q == 2) ? 4 : 0);   // (rows 8..11 and 4..7 are swapped rows)
     const int e_col = wcol0 + 4 * (m16 & 3) + (m16 >> 2);  // + 16 t: first product, m <-> sample
     const int k_col = wcol0 + 4 * q;                        // + 16 t + r: k-step r, k = q <-> sample
     double a1r[4][NKC > 0 ? NKC : 1];  // -alpha_known[k = 4 kc + q][sample]
@@ -253,6 +265,10 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
     const int last_pair = (S - 1) & ~1;
     if (ld_gcol > last_pair) ld_gcol = last_pair;
     const int d_row = lane >> 3, d_col = (lane & 7) * 8;
+    // (tile swizzle at the stores: V rows 2 i, 2 i + 1 are swapped rows for i = 2..5; the counts' rows 8 i + d_row for
+    // d_row >= 4 at i = 0 and d_row < 4 at i = 1)
+    const int ld_col_sw = ((lane & 31) ^ 2) * 2;
+    const int d_sw0 = d_row >= 4 ? 1 : 0;
     v2d pv[8];
     v4u pd[2];
     double nrt[NKC > 0 ? NKC : 1];
@@ -326,17 +342,18 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<v2d*>(tileV + (2 * i + ld_row) * kRowV + ld_col) = pv[i];
+            *reinterpret_cast<v2d*>(tileV + (2 * i + ld_row) * kRowV + ((i >= 2 && i < 6) ? ld_col_sw : ld_col)) = pv[i];
 #ifndef DMF_ABLATE_DSTORE
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            const int dsw = i == 0 ? d_sw0 : 1 - d_sw0;  // a swapped row: its two 16-byte pieces change places
             float* __restrict__ dst = tileD + (8 * i + d_row) * kRowD + d_col;
             const v4u w = pd[i];
-            *reinterpret_cast<v4f*>(dst) = v4f{(float)(w.x & 0xFFFFu), (float)(w.x >> 16), (float)(w.y & 0xFFFFu), (float)(w.y >> 16)};
-            *reinterpret_cast<v4f*>(dst + 4) = v4f{(float)(w.z & 0xFFFFu), (float)(w.z >> 16), (float)(w.w & 0xFFFFu), (float)(w.w >> 16)};
+            *reinterpret_cast<v4f*>(dst + 4 * dsw) = v4f{(float)(w.x & 0xFFFFu), (float)(w.x >> 16), (float)(w.y & 0xFFFFu), (float)(w.y >> 16)};
+            *reinterpret_cast<v4f*>(dst + 4 - 4 * dsw) = v4f{(float)(w.z & 0xFFFFu), (float)(w.z >> 16), (float)(w.w & 0xFFFFu), (float)(w.w >> 16)};
             // the same counts as balanced digits: d + 128 = b0 + 256 b1, digit 0 = b0 - 128 (b0 ^ 0x80 as i8), digit 1 = b1
             const unsigned int e0 = w.x + 0x00800080u, e1 = w.y + 0x00800080u, e2 = w.z + 0x00800080u, e3 = w.w + 0x00800080u;
-            char* __restrict__ bdst = tileB + (8 * i + d_row) * kRowB + d_col;
+            char* __restrict__ bdst = tileB + (8 * i + d_row) * kRowB + (d_col ^ (16 * dsw));
             *reinterpret_cast<v2u*>(bdst) = v2u{__builtin_amdgcn_perm(e1, e0, 0x06040200u) ^ 0x80808080u,
                                                 __builtin_amdgcn_perm(e3, e2, 0x06040200u) ^ 0x80808080u};
             *reinterpret_cast<v2u*>(bdst + 16 * kRowB) = v2u{__builtin_amdgcn_perm(e1, e0, 0x07050301u),
@@ -363,10 +380,10 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
             v4f df;
         };
         auto load_strip = [&](int t, Strip& R) {
-            const double* __restrict__ tv = tileV + m16 * kRowV + t * 16 + 4 * q;
+            const double* __restrict__ tv = tileV + m16 * kRowV + t * 16 + 4 * qs;
             R.v01 = *reinterpret_cast<const v2d*>(tv);
             R.v23 = *reinterpret_cast<const v2d*>(tv + 2);
-            R.df = *reinterpret_cast<const v4f*>(tileD + m16 * kRowD + t * 16 + 4 * q);
+            R.df = *reinterpret_cast<const v4f*>(tileD + m16 * kRowD + t * 16 + 4 * qs);
         };
         double csm0 = 0.0, csm1 = 0.0;  // c[unknown q][row m16], one double per lane
         auto e_init = [&](const Strip& R) { return v4d{R.v01.x, R.v01.y, R.v23.x, R.v23.y}; };
@@ -384,7 +401,7 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
             return en;
         };
 #ifdef DMF_ABLATE_E
-        const double csm = tileV[m16 * kRowV + 4 * q];
+        const double csm = tileV[m16 * kRowV + 4 * qs];
 #else
         Strip sa, sb;
         load_strip(0, sa);
@@ -409,11 +426,11 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
         for (int w8 = 0; w8 < 8; ++w8) mw[w8] = v4i{0, 0, 0, 0};
 #ifndef DMF_ABLATE_M  // (diagnostic builds of tools/rowpass2_probe.hip leave pieces out to see what they cost)
         {
-            const v4i c0 = *reinterpret_cast<const v4i*>(tileB + m16 * kRowB + 16 * q);  // A: counts [row m16][16 samples]
+            const v4i c0 = *reinterpret_cast<const v4i*>(tileB + m16 * kRowB + 16 * qs);  // A: counts [row m16][16 samples]
 #pragma unroll
             for (int t = 0; t < 7; ++t) mw[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(c0, pdg[t], mw[t], 0, 0, 0);
             if (nd == 2) {
-                const v4i c1 = *reinterpret_cast<const v4i*>(tileB + (16 + m16) * kRowB + 16 * q);
+                const v4i c1 = *reinterpret_cast<const v4i*>(tileB + (16 + m16) * kRowB + 16 * qs);
 #pragma unroll
                 for (int t = 0; t < 7; ++t) mw[t + 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(c1, pdg[t], mw[t + 1], 0, 0, 0);
             }
@@ -532,9 +549,10 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
         // ---- phase C: b_u[j][s] += sum_rows u[row][j] (d v)[row][s] on the 4x4x4 (4 blocks) FP64 MFMA: block = sample
         // quad of a 16-sample strip, i = unknown, j = sample in the quad, k = row in a quad of rows (A[b][i][k] sits
         // at lane 16 k + 4 b + i, B[b][k][j] at lane 16 k + 4 b + j, the result D[b][i][j] at lane 16 i + 4 b + j:
-        // tools/mfma_probe.hip).  Lane (q, m16) therefore reads (d v) of row 4 R + q, sample 16 t + m16 and u of row
-        // 4 R + q, unknown m16 & 3; the 32 tile reads of the block are independent and go out in two batches (a lane =
-        // sample loop with per-row broadcast reads of u spent ~1.6k cycles per block on LDS round trips).
+        // tools/mfma_probe.hip).  k may number the rows of a quad in any order: lane (q, m16) reads (d v) of row
+        // R + c_row(q), sample 16 t + m16 (at its swizzled place) and u of that row, unknown m16 & 3; the 32 tile reads of
+        // the block are independent and go out in two batches (a lane = sample loop with per-row broadcast reads of u
+        // spent ~1.6k cycles per block on LDS round trips).
 #ifndef DMF_ABLATE_C
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -542,11 +560,11 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
             float dd[2][4];
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const int row = 4 * (2 * half + rr) + q;
+                const int row = 2 * half + rr + c_row;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    vv[rr][t] = tileV[row * kRowV + 16 * t + m16];
-                    dd[rr][t] = tileD[row * kRowD + 16 * t + m16];
+                    vv[rr][t] = tileV[row * kRowV + 16 * t + mC];
+                    dd[rr][t] = tileD[row * kRowD + 16 * t + mC];
                 }
                 ua[rr] = (m16 & 3) < NU ? ubuf[row * NU + (m16 & 3)] : 0.0;
             }
