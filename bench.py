@@ -55,7 +55,7 @@ def algorithmic_flops(N, S, n_c, n_u, t2=T2):
     return N * S * (2 * n_c + 4 * n_u + 2 * n_u * (n_u + 1) + 2 * n_c * n_u + 4) + t2 * N * (2 * n_u * n_u + 8 * n_u)
 
 
-def make_inputs_on_device(torch, dev, N, S, n_c, n_u, seed=0):
+def make_inputs_on_device(torch, dev, N, S, n_c, n_u, seed=0, depth=None):
     """Synthetic CpG x sample data, SURVEY.md section 8(d) recipe (Beta(.5,.5) profiles, Dirichlet proportions,
     Poisson(50)+1 depth, Binomial counts).  The small factors (N x K profiles, K x S proportions) come from
     legacy numpy RandomState(seed) exactly as the recipe says; the two N x S draws (Poisson depth, Binomial
@@ -69,7 +69,8 @@ def make_inputs_on_device(torch, dev, N, S, n_c, n_u, seed=0):
     g.manual_seed(seed)
     R_d = torch.from_numpy(Rfull).to(dev)
     P = torch.clamp(R_d @ torch.from_numpy(A).to(dev), 0.0, 1.0)
-    depth = float(os.environ.get("DMF_BENCH_DEPTH", "50"))  # (experiments: depth > ~100 makes some count exceed 127 -> two count digits)
+    if depth is None:  # (experiments: depth > ~100 makes some count exceed 127 -> two count digits)
+        depth = float(os.environ.get("DMF_BENCH_DEPTH", "50"))
     D = torch.poisson(torch.full((N, S), depth, dtype=torch.float64, device=dev), generator=g) + 1.0
     X = torch.binomial(D, P, generator=g)
     V = (X / D).contiguous()

@@ -19,7 +19,8 @@ OBJ_DIR = CSRC / "build"
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-Wno-pass-failed"]
+EXPERIMENT = ["-DDMF_EXPERIMENT"] if os.environ.get("DMF_EXPERIMENT") == "1" else []
+CXXFLAGS = [*EXPERIMENT, "-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-Wno-pass-failed"]
 
 
 def _sources():

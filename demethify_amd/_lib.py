@@ -12,6 +12,8 @@ LIB_PATH = Path(__file__).resolve().parent / "libdemethify_hip.so"
 
 DMF_OK = 0
 DMF_PTR_DEVICE = 1
+DMF_INIT_IN_UNIT_RANGE = 4
+DMF_SELECT_COUNTS_F32_EXACT, DMF_SELECT_PURITY, DMF_SELECT_ALPHA_OUTSIDE_UNIT, DMF_SELECT_V_UNALIGNED = 1, 2, 4, 8
 DMF_COUNTS_F64 = 2
 DMF_MODE_PARTIAL = 0
 DMF_MODE_UNSUPERVISED = 1
@@ -51,6 +53,8 @@ SIGNATURES = {
     "dmf_solver_cost": (C.c_int, [_p, _dbl_p]),
     "dmf_solver_destroy": (C.c_int, [_p]),
     "dmf_solver_describe": (C.c_int, [_p, _i64, C.c_char_p, _i64]),
+    "dmf_select_describe": (C.c_int, [_i64, _i64, _i64, _i64, C.c_int, C.c_int, _i64, C.c_int, C.c_char_p, _i64]),
+    "dmf_solver_stop_info": (C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(_i64), _dbl_p]),
     "dmf_table_scan": (C.c_int, [C.c_char_p, C.c_char, C.POINTER(_i64), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_int)]),
     "dmf_table_read": (C.c_int, [C.c_char_p, C.c_char, C.c_int, C.c_int, _i64, _p, _i64, C.c_double, _p, _i64, C.c_int]),

@@ -13,6 +13,7 @@
 
 #include "../../include/demethify_hip.h"
 #include "dmf_internal.h"
+#include "dmf_select.h"
 
 using dmf::SolverState;
 
@@ -93,17 +94,11 @@ struct dmf_solver {
     const dmf_problem* p = nullptr;
     int64_t n_u = 0;
     int mode = 0;
-    int u_path = 0;         // 0 MFMA, 1 Gram-form VALU, 2 schedule-faithful direct steps
-    bool use_gram_spec = false;
-    bool use_gram_mfma = false;
-    bool use_u_big = false;      // 9 <= n_u <= 26: matrix-core u phase with M_i in LDS
-    bool use_cm_i8 = false;      // 5 <= n_u <= 16 with u16 counts: split u phase, M_i on the integer matrix cores
+    dmf::ShapeKey key;      // what the kernel selection looks at (dmf_select.h) ...
+    dmf::PathSpec spec;     // ... and what it fixed for this solver
     double* cm = nullptr;        // split u phase (many inner steps): per-row c_i / M_i, allocated on first use
     double* beta_tab = nullptr;  //   and the momentum coefficients of the inner steps
-    int64_t beta_cap = 0;  // shapes beyond the lane-per-sample kernel's registers: MFMA Gram
-    bool use_fused = false;      // first-generation fused row pass (counts as f64 in HBM, FP64 Gram in the kernel)
-    bool use_v2 = false;         // second generation: u16 counts in the row pass + integer-MFMA Gram
-    bool use_gram_i8 = false;    // u phase as a kernel of its own (n_u > 4 ...), Gram on the integer matrix cores + k_bu_cols
+    int64_t beta_cap = 0;
     long long* slab_i8 = nullptr;   // i64 partial sums of the integer Gram (one slab per row range)
     int64_t slab_i8_words = 0;
     long long* acc_i8 = nullptr;    // reduction scratch of the integer Gram (kept zero between iterations)
@@ -120,6 +115,20 @@ struct dmf_solver {
     short *job_k = nullptr, *job_l = nullptr;
     int* job_dst = nullptr;
     int n_jobs = 0;
+    std::vector<short> h_job_k, h_job_l;  // (the uploads of the job table read these: kept for the solver's life, so that
+    std::vector<int> h_job_dst;           //  dmf_solver_create need not wait for them)
+    // deconvolution.py:204 -- the cost before the loop is only ever read by the first stop test (:220): it is computed when
+    // a step() call with tol > 0 (or a get() before any iteration) needs it, one 0.5 ms pass over V and D at 1e6 x 256
+    bool cf_pending = true;
+    // Stop test (:218-220).  The loop's cost comes from the Gram form v^T D v - 2 a.b + a^T G a, whose cancellation error
+    // grows with v^T D v (1e-3 absolute at 1e6 x 256, depth 50; 5e-2 at depth 2500) -- where that is not far below tol
+    // (confirm_stops), an iteration whose Gram-form |cf - cf_0| falls below kConfirmBand x tol pauses the device
+    // (state->done = 2), and the host decides on the streaming cost of deconvolution.py:15-17 for this and the previous
+    // iterate (cf_stream, cf_stream_iter), exactly the reference's formula.
+    bool confirm_stops = false;
+    double cf_stream = 0.0;
+    long long cf_stream_iter = -1;
+    long long n_confirmed = 0, n_unconfirmed = 0;  // stop tests decided on streaming costs / on the Gram form inside the band
 };
 
 namespace {
@@ -404,7 +413,7 @@ int check_ctx(dmf_context* ctx) {
     return DMF_OK;
 }
 
-constexpr int kSplitInnerSteps = 50;  // beyond this the unfused / split u phase beats the fused kernel
+using dmf::kSplitInnerSteps;
 
 // scratch of the split u phase: per-row c_i / M_i and the momentum coefficients of the inner steps (allocated on first use)
 int ensure_split_scratch(dmf_solver* s, int n_iter2) {
@@ -421,67 +430,69 @@ int ensure_split_scratch(dmf_solver* s, int n_iter2) {
     return DMF_OK;
 }
 
-int enqueue_u_phase(dmf_solver* s, int n_iter2) {
+int enqueue_u_phase(dmf_solver* s, int n_iter2, dmf::RowKind row) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
     FamilyScope scope(ctx, DMF_KERNEL_ROWPASS);
-    if (s->use_cm_i8) {
-        // wide row groups on u16 counts: per-row c_i / M_i with M_i on the integer matrix cores, then the inner iterations
-        // chip-wide (dmf_kernels_cm_i8.hip)
-        DMF_TRY(ensure_split_scratch(s, n_iter2));
-        HIP_TRY(dmf::launch_u_phase_split_i8(p->V, p->D16, p->SD, p->ND, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N,
-                                             (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, s->cm, s->beta_tab,
-                                             ctx->stream));
-        return DMF_OK;
+    switch (row) {
+        case dmf::RowKind::CmI8InnerRows:
+            // wide row groups on u16 counts: per-row c_i / M_i with M_i on the integer matrix cores, then the inner
+            // iterations chip-wide (dmf_kernels_cm_i8.hip)
+            DMF_TRY(ensure_split_scratch(s, n_iter2));
+            HIP_TRY(dmf::launch_u_phase_split_i8(p->V, p->D16, p->SD, p->ND, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N,
+                                                 (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, s->cm, s->beta_tab,
+                                                 ctx->stream));
+            return DMF_OK;
+        case dmf::RowKind::UPhaseBig:
+            HIP_TRY(dmf::launch_u_phase_big(p->V, p->D, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, (int)p->S,
+                                            (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
+            return DMF_OK;
+        case dmf::RowKind::UPhaseMfmaSplit:
+            // many inner steps or wide row groups: one wave per workgroup running the inner steps is the bottleneck
+            DMF_TRY(ensure_split_scratch(s, n_iter2));
+            HIP_TRY(dmf::launch_u_phase_split(p->V, p->D, p->D16, p->SD, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N,
+                                              (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, s->cm, s->beta_tab,
+                                              ctx->stream));
+            return DMF_OK;
+        case dmf::RowKind::UPhaseMfma:
+            HIP_TRY(dmf::launch_u_phase_mfma(p->V, p->D, p->D16, p->SD, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N,
+                                             (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
+            return DMF_OK;
+        case dmf::RowKind::UPhaseGram:
+            HIP_TRY(dmf::launch_u_phase_gram(p->V, p->D, p->Rt, s->alpha, s->u, s->u_prev, s->state, p->N,
+                                             (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
+            return DMF_OK;
+        case dmf::RowKind::UStepDirect:
+            for (int t = 0; t < n_iter2; ++t) {
+                HIP_TRY(dmf::launch_u_step_direct(p->V, p->D, p->Rt, s->alpha, s->u, s->u_prev, s->u_next,
+                                                  s->state, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, t,
+                                                  s->mode, ctx->stream));
+                double* old_prev = s->u_prev;
+                s->u_prev = s->u;
+                s->u = s->u_next;
+                s->u_next = old_prev;
+            }
+            return DMF_OK;
+        default: return DMF_ERR_BAD_ARG;  // (the one-launch row passes are enqueue_outer_iteration's)
     }
-    if (s->use_u_big && dmf::u_phase_big_supported((int)p->S, (int)p->n_c, (int)s->n_u, n_iter2)) {
-        HIP_TRY(dmf::launch_u_phase_big(p->V, p->D, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, (int)p->S,
-                                        (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
-        return DMF_OK;
-    }
-    // The split form also wins at few inner steps once the row groups are wide: with 7 or 8 unknowns the inner steps
-    // inside k_u_phase_mfma broadcast through ds_bpermute on ONE wave per workgroup and the kernel spills (measured at
-    // 5e5 x 128, 20 steps: 0+8 0.70 -> 0.57 ms, 12+6 0.62 -> 0.48; 0+5 equal, 0+6 0.37 -> 0.39): split from 7 unknowns
-    // on, and from 5 when there are known types (their E product already fills the row kernel).
-    // DMF_SPLIT_NU=n moves the threshold (experiments).
-    static const int split_nu = [] {
-        const char* v = getenv("DMF_SPLIT_NU");
-        return v != nullptr && atoi(v) > 0 ? atoi(v) : 7;
-    }();
-    if (s->u_path == 0 && (n_iter2 > kSplitInnerSteps || (int)s->n_u >= split_nu || (p->n_c > 0 && s->n_u >= 5))) {
-        // many inner steps: one wave per workgroup running them is the bottleneck (see enqueue_outer_iteration)
-        DMF_TRY(ensure_split_scratch(s, n_iter2));
-        HIP_TRY(dmf::launch_u_phase_split(p->V, p->D, p->D16, p->SD, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N, (int)p->S,
-                                          (int)p->n_c, (int)s->n_u, n_iter2, s->mode, s->cm, s->beta_tab, ctx->stream));
-        return DMF_OK;
-    }
-    if (s->u_path == 0) {
-        HIP_TRY(dmf::launch_u_phase_mfma(p->V, p->D, p->D16, p->SD, p->Rtp, s->alpha, s->u, s->u_prev, s->state, p->N,
-                                         (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
-    } else if (s->u_path == 1) {
-        HIP_TRY(dmf::launch_u_phase_gram(p->V, p->D, p->Rt, s->alpha, s->u, s->u_prev, s->state, p->N,
-                                         (int)p->S, (int)p->n_c, (int)s->n_u, n_iter2, s->mode, ctx->stream));
-    } else {
-        for (int t = 0; t < n_iter2; ++t) {
-            HIP_TRY(dmf::launch_u_step_direct(p->V, p->D, p->Rt, s->alpha, s->u, s->u_prev, s->u_next,
-                                              s->state, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, t,
-                                              s->mode, ctx->stream));
-            double* old_prev = s->u_prev;
-            s->u_prev = s->u;
-            s->u = s->u_next;
-            s->u_next = old_prev;
-        }
-    }
-    return DMF_OK;
 }
 
-int enqueue_gram(dmf_solver* s, bool after_u_phase = false) {
+// the row kind of a u phase that runs as a kernel of its own (the single-function entry points: dmf_update_u)
+dmf::RowKind standalone_row_kind(const dmf_solver* s, int n_iter2) {
+    dmf::PathSpec spec = s->spec;
+    spec.use_v2 = false;  // (plan_iteration then describes the split / fall-back u phase of this solver)
+    spec.use_fused = false;
+    spec.use_gram_i8 = false;
+    return dmf::plan_iteration(s->key, spec, n_iter2, false).row;
+}
+
+// kind: GramKind::BuColsI8 only behind a u phase with at least one inner step (its clip puts u inside [0, 1], which the
+// fixed-point features need); the dmf_update_alpha entry point hands over the caller's u and passes an FP64 kind
+int enqueue_gram(dmf_solver* s, dmf::GramKind kind) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
     FamilyScope scope(ctx, DMF_KERNEL_GRAM);
-    if (s->use_gram_i8 && after_u_phase) {
-        // (only behind a u phase: its clip puts u inside [0, 1], which the fixed-point features need; the
-        // dmf_update_alpha entry point hands over the caller's u and stays on the FP64 kernels)
+    if (kind == dmf::GramKind::BuColsI8) {
         const int S = (int)p->S, n_c = (int)p->n_c, n_u = (int)s->n_u, nf = n_c * n_u + n_u * (n_u + 1) / 2;
         int n_slabs = 0, ny = 0;
         HIP_TRY(dmf::launch_bu_cols(p->V, p->D16, p->SD, s->u, p->N, S, n_u, s->slab, &s->state->done, &n_slabs, ctx->stream));
@@ -491,7 +502,7 @@ int enqueue_gram(dmf_solver* s, bool after_u_phase = false) {
                                            &s->state->done, nullptr, 0, s->state, ctx->stream));
         return DMF_OK;
     }
-    if (s->use_gram_spec) {
+    if (kind == dmf::GramKind::GramU) {
         int ny = 0;
         HIP_TRY(dmf::launch_gram_u(p->V, p->D, p->Rtp, s->u, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, s->slab,
                                    &s->state->done, &ny, ctx->stream));
@@ -500,7 +511,7 @@ int enqueue_gram(dmf_solver* s, bool after_u_phase = false) {
         return DMF_OK;
     }
     dmf::GramJobTable jobs{s->job_k, s->job_l, s->job_dst, s->n_jobs};
-    if (s->use_gram_mfma) {
+    if (kind == dmf::GramKind::GramMfma) {
         int ny = 0;
         HIP_TRY(dmf::launch_gram_mfma(p->V, p->D, p->Rt, s->u, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, jobs,
                                       s->n_jobs - (int)s->n_u, s->slab, s->slab_doubles, &s->state->done, &ny,
@@ -512,6 +523,10 @@ int enqueue_gram(dmf_solver* s, bool after_u_phase = false) {
     HIP_TRY(dmf::launch_gram(p->V, p->D, p->Rt, s->u, p->N, (int)p->S, (int)p->n_c, (int)s->n_u, jobs,
                              s->slab, s->slab_doubles, s->gb, &s->state->done, ctx->stream));
     return DMF_OK;
+}
+
+dmf::GramKind fp64_gram_kind(const dmf_solver* s) {
+    return s->spec.use_gram_spec ? dmf::GramKind::GramU : s->spec.use_gram_mfma ? dmf::GramKind::GramMfma : dmf::GramKind::Gram;
 }
 
 int enqueue_alpha_phase(dmf_solver* s, int n_iter2) {
@@ -532,12 +547,9 @@ int enqueue_alpha_phase(dmf_solver* s, int n_iter2) {
 int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
     dmf_context* ctx = s->ctx;
     const dmf_problem* p = s->p;
-    // With many inner steps the row-local iterations (one wave per workgroup in the fused kernel) dominate and
-    // the unfused u-phase kernel, which keeps three workgroups per CU busy, wins: measured at the headline size
-    // with n_iter2 = 500 (the CLI default under --purity) 18.5 ms fused against 7.6 + 1.2 ms; the estimated
-    // break-even is around 50 inner steps.
-    if (s->use_v2 && n_iter2 <= kSplitInnerSteps &&
-        dmf::rowpass_v2_supported((int)p->S, (int)p->n_c, (int)s->n_u, n_iter2)) {
+    // which kernels: dmf_select.hip (one table for create / enqueue / describe)
+    const dmf::IterationPlan plan = dmf::plan_iteration(s->key, s->spec, n_iter2, s->purity != nullptr);
+    if (plan.row == dmf::RowKind::RowpassV2) {
         // Second generation: one read of V (f64) and of the u16 counts for the u phase and b_u, then the exact
         // integer-matrix-core GEMM for the u-dependent Gram entries on the 8-bit count planes.
         const int S = (int)p->S, n_c = (int)p->n_c, n_u = (int)s->n_u;
@@ -558,8 +570,7 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
         DMF_TRY(enqueue_alpha_phase(s, n_iter2));
         return DMF_OK;
     }
-    if (s->use_cm_i8 && s->use_gram_i8 &&
-        dmf::u_inner_bu_supported(p->V, (int)p->S, p->SD, (int)s->n_u, n_iter2)) {
+    if (plan.row == dmf::RowKind::CmI8InnerBu) {
         // Wide row groups on u16 counts: c_i / M_i (M_i on the integer matrix cores), then the inner iterations fused with
         // the b_u stream and the ||u||^2 shares, then the integer Gram and its reduce -- four launches + the momentum table.
         const int S = (int)p->S, n_c = (int)p->n_c, n_u = (int)s->n_u;
@@ -582,7 +593,7 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
         DMF_TRY(enqueue_alpha_phase(s, n_iter2));
         return DMF_OK;
     }
-    if (s->use_fused && n_iter2 <= kSplitInnerSteps) {
+    if (plan.row == dmf::RowKind::RowpassFused) {
         // The fused kernel takes whole 16-row blocks; a ragged tail (< 16 rows) goes through the unfused
         // pair on offset pointers and contributes extra slab rows and one more ||u||^2 share.
         const int64_t n_full = p->N - (p->N & 15), n_tail = p->N - n_full;
@@ -614,11 +625,11 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
         DMF_TRY(enqueue_alpha_phase(s, n_iter2));
         return DMF_OK;
     }
-    DMF_TRY(enqueue_u_phase(s, n_iter2));
+    DMF_TRY(enqueue_u_phase(s, n_iter2, plan.row));
     HIP_TRY(dmf::launch_sumsq_f64(s->u, p->N * s->n_u, ctx->scratch, &s->state->u_norm2, &s->state->done,
                                   ctx->stream));
     HIP_TRY(dmf::launch_set_lh(s->state, ctx->stream));
-    DMF_TRY(enqueue_gram(s, true));
+    DMF_TRY(enqueue_gram(s, plan.gram));
     DMF_TRY(enqueue_alpha_phase(s, n_iter2));
     return DMF_OK;
 }
@@ -962,77 +973,55 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     s->p = p;
     s->n_u = n_u;
     s->mode = mode;
-    const bool fast = ctx->generic_level == 0 || ctx->generic_level == 3 || ctx->generic_level == 4;
-    if (fast && dmf::u_phase_mfma_supported((int)S, (int)n_c, (int)n_u)) s->u_path = 0;
-    else if (ctx->generic_level != 2 && dmf::u_phase_gram_supported((int)S, (int)n_c, (int)n_u)) s->u_path = 1;
-    else s->u_path = 2;
-    s->use_gram_spec = fast && dmf::gram_u_supported((int)n_c, (int)n_u);
-    s->use_gram_mfma = fast && !s->use_gram_spec;
-    s->use_u_big = fast && s->u_path != 0 && dmf::u_phase_big_supported((int)S, (int)n_c, (int)n_u, 64);
-    s->use_v2 = ctx->generic_level == 0 && p->ND > 0 && p->D16 != nullptr && (n_c == 0 || p->Rtp != nullptr) &&
-                (reinterpret_cast<uintptr_t>(p->V) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0 &&
-                dmf::rowpass_v2_supported((int)S, (int)n_c, (int)n_u, 20) &&
-                dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
-    // Wide row groups (n_u 5..16) on u16 counts: the split u phase with the integer-matrix-core producer.  Measured at
-    // 5e5 x 128 against what ran before: see DESIGN.md section 5.  DMF_CM_I8_MIN_NU moves the lower end (experiments).
-    static const int cm_min_nu = [] { const char* v = getenv("DMF_CM_I8_MIN_NU"); return v != nullptr && atoi(v) > 0 ? atoi(v) : 5; }();
-    // (narrow row groups reach it beyond the row pass's 512 samples -- the producer walks panels of 256 samples -- and
-    // with more than 16 known types)
-    s->use_cm_i8 = ctx->generic_level == 0 && !s->use_v2 && p->ND > 0 && p->D16 != nullptr && (n_u >= cm_min_nu || S > 512 || n_c > 16) && n_u <= 32 &&
-                   (n_c == 0 || (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 7) == 0)) &&
-                   dmf::cm_i8_supported(p->V, (int)S, (int)n_c, (int)n_u, p->ND, p->SD);
-    // shapes the second-generation row pass does not take (n_u 5..20, long inner loops): the u phase stays a kernel of its
-    // own, the Gram pass becomes the integer GEMM + the b_u stream kernel (V f64 + u16 counts instead of V and D f64
-    // and n_u (n_u + 3) / 2 + n_c n_u FP64 FMAs per element)
-    // Measured at 5e5 x 128 (tools/gram_i8_vs_fp64.py): 6+6 (57 features) 0.25 against 0.35 ms for k_gram_u, but 0+5 / 0+8 /
-    // 0+12 0.25 / 0.25 / 0.34 against 0.19 / 0.22 / 0.31 ms -- without known types the FP64 Gram is cheap and the four
-    // launches of this route are not; so: only with known types and at least 40 features.
-    // What the integer route competes with is k_gram_u, whose time grows with its accumulator count (padded known types
-    // x unknowns + pairs + b_u) while the integer route is flat (k_bu_cols dominates it): at 5e5 x 128 the FP64 kernel
-    // takes 0.21 ms with 51 accumulators (2+6, 4+6), 0.23 with 40 (1+5, 3+5), 0.36 with 60..76 (5+5, 1+8, 3+8), the
-    // integer route 0.20..0.21 throughout with two samples per lane in k_bu_cols2 (tools/gram_i8_vs_fp64.py): from 48
-    // accumulators on.  DMF_GRAM_I8_MIN moves the threshold (experiments).
-    static const int i8_min_features = [] { const char* v = getenv("DMF_GRAM_I8_MIN"); return v != nullptr ? atoi(v) : 48; }();
-    const int fp64_acc = (int)((n_c + 3) / 4 * 4 * n_u + n_u * (n_u + 1) / 2 + n_u);
-    static const int i8_min_nc0 = [] { const char* v = getenv("DMF_GRAM_I8_MIN_NC0"); return v != nullptr ? atoi(v) : 33; }();
-    // (without known types: from 8 unknowns -- 36 features -- on.  At 5e5 x 128 with k_bu_cols2 up to 16 unknowns:
-    // 0+8 0.24 -> 0.20 ms, 0+12 0.36 -> 0.29, 0+16 0.67 (k_gram_mfma) -> 0.36; below 8 k_gram_u is cheaper.)
-    // Behind k_cm_i8 the b_u stream rides along with the inner iterations (k_inner_bu) and the integer route is what is
-    // left of the Gram pass: it then wins at every width (0+5 / 0+6 / 0+7 at 5e5 x 128: 0.58 / 0.55 / 0.59 -> 0.51 / 0.49 /
-    // 0.53 ms per iteration against k_gram_u).
-    const bool fused_bu = s->use_cm_i8 && dmf::u_inner_bu_supported(p->V, (int)S, p->SD, (int)n_u, 20);
-    const bool known_ok = n_c > 0 ? (p->Rtp != nullptr && (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0) : true;
-    s->use_gram_i8 = ctx->generic_level == 0 && p->ND > 0 && p->D16 != nullptr && known_ok &&
-                     (fused_bu || (n_c > 0 ? fp64_acc >= i8_min_features : n_u * (n_u + 1) / 2 >= i8_min_nc0)) && n_u <= 32 &&
-                     dmf::gram_i8_supported((int)n_c, (int)n_u, p->ND, N, p->SD);
-    if (s->use_v2 || s->use_cm_i8) {
-        // the row pass writes alpha_j alpha_l in fixed point on [0, 1]: true of every iterate (columns on the simplex),
-        // checked for the caller's starting point
-        std::vector<double> ha((size_t)K * S);
-        hipError_t ec = hipMemcpyAsync(ha.data(), alpha0, ha.size() * sizeof(double),
-                                       (flags & DMF_PTR_DEVICE) ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, ctx->stream);
-        if (ec == hipSuccess) ec = hipStreamSynchronize(ctx->stream);
-        if (ec != hipSuccess) {
-            delete s;
-            return hip_fail(ec, "copy alpha0", __LINE__);
-        }
-        for (double a : ha)
-            if (!(a >= 0.0 && a <= 1.0)) {
-                s->use_v2 = false;
-                s->use_cm_i8 = false;
-                break;
+    // ---- kernel selection: a pure function of this key (dmf_select.hip)
+    dmf::ShapeKey& key = s->key;
+    key.N = N;
+    key.S = (int)S;
+    key.n_c = (int)n_c;
+    key.n_u = (int)n_u;
+    key.nd = (p->ND > 0 && p->D16 != nullptr) ? p->ND : 0;
+    key.SD = p->SD;
+    key.level = ctx->generic_level;
+    key.d_f32_exact = p->d_f32_exact;
+    key.rtp_present = n_c == 0 || p->Rtp != nullptr;
+    key.v_align = (unsigned)(reinterpret_cast<uintptr_t>(p->V) & 15);
+    key.rtp_align = (unsigned)(reinterpret_cast<uintptr_t>(p->Rtp) & 15);
+    key.alpha_unit = true;
+    s->spec = dmf::select_path(key);
+    if ((s->spec.use_v2 || s->spec.use_cm_i8) && !(flags & DMF_INIT_IN_UNIT_RANGE)) {
+        // the integer row kernels write alpha_j alpha_l in fixed point on [0, 1]: true of every iterate (columns on the
+        // simplex), checked for the caller's starting point -- in place for a host array, by a kernel for a device array
+        // (callers that know where their alpha0 comes from say so with DMF_INIT_IN_UNIT_RANGE and skip the round trip)
+        bool in_unit = true;
+        if (flags & DMF_PTR_DEVICE) {
+            double outside = 0.0;
+            hipError_t ec = dmf::launch_unit_range_check(alpha0, K * S, ctx->scratch, ctx->scratch + 2048, ctx->stream);
+            if (ec == hipSuccess) ec = hipMemcpyAsync(&outside, ctx->scratch + 2048, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+            if (ec == hipSuccess) ec = hipStreamSynchronize(ctx->stream);
+            if (ec != hipSuccess) {
+                delete s;
+                return hip_fail(ec, "check alpha0", __LINE__);
             }
+            in_unit = outside == 0.0;
+        } else {
+            for (int64_t i = 0; i < K * S; ++i)
+                if (!(alpha0[i] >= 0.0 && alpha0[i] <= 1.0)) {
+                    in_unit = false;
+                    break;
+                }
+        }
+        if (!in_unit) {
+            key.alpha_unit = false;
+            s->spec = dmf::select_path(key);
+        }
     }
-    s->use_fused = (ctx->generic_level == 0 || ctx->generic_level == 4) && p->d_f32_exact && N >= 16 &&
-                   dmf::rowpass_fused_supported((int)S, (int)n_c, (int)n_u) &&
-                   dmf::u_phase_mfma_supported((int)S, (int)n_c, (int)n_u) && dmf::gram_u_supported((int)n_c, (int)n_u);
-    if (s->u_path == 2 && !dmf::u_step_direct_supported((int)S, (int)n_c, (int)n_u)) {
+    if (!s->spec.supported) {
         delete s;
         return DMF_ERR_UNSUPPORTED;
     }
     // job table of the per-iteration part of the packed Gram: every (k, l) that involves u
-    std::vector<short> hk, hl;
-    std::vector<int> hd;
+    std::vector<short>&hk = s->h_job_k, &hl = s->h_job_l;
+    std::vector<int>& hd = s->h_job_dst;
     for (int l = (int)n_c; l <= (int)K; ++l)
         for (int k = 0; k <= l; ++k) {
             if (l == (int)K && k < (int)n_c) continue;  // b of the known types is constant
@@ -1043,27 +1032,27 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
         }
     s->n_jobs = (int)hk.size();
     s->slab_doubles = dmf::gram_slab_doubles(N, (int)S, s->n_jobs);
-    if (s->use_gram_spec) {
+    if (s->spec.use_gram_spec) {
         const int64_t spec = dmf::gram_u_slab_doubles(N, (int)S, (int)n_c, (int)n_u);
         if (spec > s->slab_doubles) s->slab_doubles = spec;
     }
-    if (s->use_gram_mfma) {
+    if (s->spec.use_gram_mfma) {
         const int64_t need = dmf::gram_mfma_slab_doubles(N, (int)S, s->n_jobs);
         if (need > s->slab_doubles) s->slab_doubles = need;
     }
-    if (s->use_fused) {
+    if (s->spec.use_fused) {
         const int64_t spec = dmf::rowpass_fused_slab_doubles(N - (N & 15), (int)S, (int)n_c, (int)n_u) +
                              dmf::gram_u_slab_doubles(16, (int)S, (int)n_c, (int)n_u);  // + ragged tail rows
         if (spec > s->slab_doubles) s->slab_doubles = spec;
     }
-    if (s->use_v2) {
+    if (s->spec.use_v2) {
         const int64_t bu = (int64_t)dmf::rowpass_v2_grid(N, (int)S) * n_u * S;
         if (bu > s->slab_doubles) s->slab_doubles = bu;
     }
-    if (s->use_gram_i8) {
+    if (s->spec.use_gram_i8) {
         const int64_t bu = (int64_t)dmf::bu_cols_grid(N) * n_u * S;
         if (bu > s->slab_doubles) s->slab_doubles = bu;
-        if (s->use_cm_i8) {  // k_inner_bu writes one slab per workgroup
+        if (s->spec.use_cm_i8) {  // k_inner_bu writes one slab per workgroup
             const int64_t bu2 = (int64_t)dmf::u_inner_bu_grid(N, (int)S) * n_u * S;
             if (bu2 > s->slab_doubles) s->slab_doubles = bu2;
         }
@@ -1074,18 +1063,18 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     const int nb_alpha = (int)((S + 63) / 64);
     hipError_t e = pool_alloc(ctx, (void**)&s->u, un_alloc);
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->u_prev, un_alloc);
-    if (e == hipSuccess && s->u_path == 2) e = pool_alloc(ctx, (void**)&s->u_next, un_alloc);
+    if (e == hipSuccess && s->spec.u_path == 2) e = pool_alloc(ctx, (void**)&s->u_next, un_alloc);
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->alpha, an);
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->alpha_prev, an);
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->gb, gbn);
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->slab, (size_t)s->slab_doubles * sizeof(double));
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->partials, (size_t)2 * (nb_alpha + S) * sizeof(double));
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->u2_partials, 4096 * sizeof(double));
-    if (e == hipSuccess && (s->use_v2 || s->use_gram_i8)) {
+    if (e == hipSuccess && (s->spec.use_v2 || s->spec.use_gram_i8)) {
         s->slab_i8_words = dmf::gram_i8_slab_words(N, p->SD, (int)n_c, (int)n_u);
         e = pool_alloc(ctx, (void**)&s->slab_i8, (size_t)s->slab_i8_words * sizeof(long long));
     }
-    if (e == hipSuccess && (s->use_v2 || s->use_gram_i8)) {
+    if (e == hipSuccess && (s->spec.use_v2 || s->spec.use_gram_i8)) {
         const size_t bytes = (size_t)dmf::gram_i8_acc_words((int)S, (int)n_c, (int)n_u) * sizeof(long long);
         e = pool_alloc(ctx, (void**)&s->acc_i8, bytes);
         if (e == hipSuccess) e = hipMemsetAsync(s->acc_i8, 0, bytes, ctx->stream);
@@ -1114,12 +1103,12 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     if (e == hipSuccess) e = hipMemcpyAsync(s->job_dst, hd.data(), s->n_jobs * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = dmf::launch_scatter_known_block(p->gb_known, s->gb, (int)n_c, (int)K, (int)S, ctx->stream);
     if (e == hipSuccess) e = dmf::launch_sumsq_f64(s->u, N * n_u, ctx->scratch, &s->state->u_norm2, nullptr, ctx->stream);
-    if (e == hipSuccess) {
-        FamilyScope scope(ctx, DMF_KERNEL_COST);
-        e = enqueue_cost(ctx, p, s->u, s->alpha, (int)n_u, ctx->scratch + 1024, &s->state->cf);
-    }
+    // (the cost before the loop, deconvolution.py:204: when a stop test needs it -- dmf_solver_step)
     if (e == hipSuccess) e = dmf::launch_init_state(s->state, p->consts, s->alpha, (int)S, (int)n_c, (int)n_u, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host job vectors go out of scope
+    // Where the Gram-form cost of the loop may be off by a noticeable share of a stop threshold, stops are confirmed with
+    // the streaming cost (see dmf_solver): the form's absolute error grows with v^T D v <= N S max(D); measured 1e-3 at
+    // 1e6 x 256 x depth 50 (v^T D v = 4.5e9), i.e. ~2e-13 v^T D v.  kGramCostRelErr x N S max(D) bounds it with margin.
+    s->confirm_stops = false;  // (set per step() call from tol)
     if (e != hipSuccess) {
         dmf_solver_destroy(s);
         return hip_fail(e, "solver set-up", __LINE__);
@@ -1128,31 +1117,89 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     return DMF_OK;
 }
 
-__global__ void k_set_tol(SolverState* state, double tol) { state->tol = tol; }
+// tol and the band factor of this step() call: the closing kernel pauses (done = 2) when |cf - cf_0| < band x tol
+// with band > 1, and stops (done = 1) when band == 1
+__global__ void k_set_tol(SolverState* state, double tol, double band) {
+    state->tol = tol;
+    state->band = band;
+}
+
+constexpr double kConfirmBand = 10.0;       // Gram-form differences below this multiple of tol are decided on streaming costs
+constexpr double kGramCostRelErr = 2.5e-13; // bound of the Gram-form cost's absolute error, per unit of N S max(D) (above)
+
+// streaming cost of the solver's current iterate (deconvolution.py:15-17) to the host
+static int stream_cost_now(dmf_solver* s, double* out) {
+    dmf_context* ctx = s->ctx;
+    {
+        FamilyScope scope(ctx, DMF_KERNEL_COST);
+        HIP_TRY(enqueue_cost(ctx, s->p, s->u, s->alpha, (int)s->n_u, ctx->scratch + 1024, ctx->scratch + 3072));
+    }
+    HIP_TRY(hipMemcpyAsync(out, ctx->scratch + 3072, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DMF_OK;
+}
 
 int dmf_solver_step(dmf_solver* s, int64_t n_outer, int64_t n_iter2, double tol,
                     int64_t* iters_done_total, int* converged) {
     if (s == nullptr || n_outer < 0 || n_iter2 < 0 || n_iter2 > (1 << 20)) return DMF_ERR_BAD_ARG;
     dmf_context* ctx = s->ctx;
     DMF_TRY(check_ctx(ctx));
-    hipLaunchKernelGGL(k_set_tol, dim3(1), dim3(1), 0, ctx->stream, s->state, tol);
+    const dmf_problem* p = s->p;
+    // Stops are confirmed with streaming costs where the Gram form's error bound is not far below the threshold.
+    const double gram_err = kGramCostRelErr * (double)p->N * (double)p->S * p->h_consts[2];
+    s->confirm_stops = tol > 0.0 && gram_err >= tol / 20.0;
+    hipLaunchKernelGGL(k_set_tol, dim3(1), dim3(1), 0, ctx->stream, s->state, tol, s->confirm_stops ? kConfirmBand : 1.0);
     HIP_TRY(hipGetLastError());
+    if (s->cf_pending && tol > 0.0 && n_outer > 0) {
+        // deconvolution.py:204: the cost before the loop, read by the first stop test only (a threshold of zero never fires)
+        FamilyScope scope(ctx, DMF_KERNEL_COST);
+        HIP_TRY(enqueue_cost(ctx, p, s->u, s->alpha, (int)s->n_u, ctx->scratch + 1024, &s->state->cf));
+        s->cf_pending = false;
+        s->cf_stream_iter = -2;  // (marks: state->cf of iteration 0 IS a streaming cost; resolved at the first fetch below)
+    }
     DMF_TRY(fetch_state(s));
+    if (s->cf_stream_iter == -2) {
+        s->cf_stream = s->h_state->cf;
+        s->cf_stream_iter = s->h_state->iters;
+    }
     // The device freezes the iterate once the stop test fires (every kernel checks state->done),
     // so the host may run ahead by `check_every` enqueued iterations without overshooting.
     // The batches double (8, 16, 32, 64): a solve that runs for hundreds of iterations reads the state back a handful of
     // times, and what a late stop costs is a few dozen no-op launches.
-    int64_t check_every = s->u_path != 2 ? 8 : 1;
-    int64_t enqueued = 0;
-    while (enqueued < n_outer && !s->h_state->done) {
-        int64_t batch = n_outer - enqueued < check_every ? n_outer - enqueued : check_every;
+    int64_t check_every = s->spec.u_path != 2 ? 8 : 1;
+    const long long iters0 = s->h_state->iters;
+    while (s->h_state->iters - iters0 < n_outer && s->h_state->done != 1) {
+        const int64_t left = n_outer - (s->h_state->iters - iters0);
+        const int64_t batch = left < check_every ? left : check_every;
         for (int64_t b = 0; b < batch; ++b) DMF_TRY(enqueue_outer_iteration(s, (int)n_iter2));
-        enqueued += batch;
         DMF_TRY(fetch_state(s));
-        if (s->u_path != 2 && check_every < 64) check_every *= 2;
+        if (s->h_state->iters > iters0) s->cf_pending = false;  // (state->cf is the loop's cost from now on)
+        if (s->h_state->done == 2) {
+            // Paused inside the band at iteration h_state->iters (launches enqueued behind it were no-ops): decide
+            // |cf - cf_0| < tol on the streaming costs of this and the previous iterate -- the reference's own formula.
+            // The previous one is known when that iteration paused too (or was the starting point); the first
+            // iteration inside the band has only the Gram form to go by.
+            double cs = 0.0;
+            DMF_TRY(stream_cost_now(s, &cs));
+            bool stop;
+            if (s->cf_stream_iter == s->h_state->iters - 1) {
+                stop = std::fabs(cs - s->cf_stream) < tol;
+                s->n_confirmed += 1;
+            } else {
+                stop = std::fabs(s->h_state->cf - s->h_state->cf_prev) < tol;
+                s->n_unconfirmed += 1;
+            }
+            s->cf_stream = cs;
+            s->cf_stream_iter = s->h_state->iters;
+            s->h_state->done = stop ? 1 : 0;
+            DMF_TRY(push_state(s));
+            check_every = 1;  // (stay close: the next iterations are likely to pause again)
+        } else if (s->spec.u_path != 2 && check_every < 64 && check_every > 1) {
+            check_every *= 2;
+        }
     }
     if (iters_done_total) *iters_done_total = s->h_state->iters;
-    if (converged) *converged = s->h_state->done;
+    if (converged) *converged = s->h_state->done == 1;
     return DMF_OK;
 }
 
@@ -1177,6 +1224,11 @@ int dmf_solver_get(dmf_solver* s, int flags, double* out_u, double* out_alpha, d
     const dmf_problem* p = s->p;
     DMF_TRY(export_array(ctx, s->u, (size_t)p->N * s->n_u * sizeof(double), flags, out_u));
     DMF_TRY(export_array(ctx, s->alpha, (size_t)(p->n_c + s->n_u) * p->S * sizeof(double), flags, out_alpha));
+    if (s->cf_pending && out_cost != nullptr) {  // no iteration has run: the cost of the starting point, now
+        FamilyScope scope(ctx, DMF_KERNEL_COST);
+        HIP_TRY(enqueue_cost(ctx, p, s->u, s->alpha, (int)s->n_u, ctx->scratch + 1024, &s->state->cf));
+        s->cf_pending = false;
+    }
     DMF_TRY(fetch_state(s));
     if (out_cost) *out_cost = s->h_state->cf;
     if (out_iters) *out_iters = s->h_state->iters;
@@ -1226,43 +1278,44 @@ int dmf_solver_destroy(dmf_solver* s) {
 }
 
 int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t cap) {
-    if (s == nullptr || buf == nullptr || cap < 1) return DMF_ERR_BAD_ARG;
-    const dmf_problem* p = s->p;
-    const int S = (int)p->S, n_c = (int)p->n_c, n_u = (int)s->n_u, K = n_c + n_u;
-    char row[160], gram[64];
-    if (s->use_v2 && n_iter2 <= kSplitInnerSteps && dmf::rowpass_v2_supported(S, n_c, n_u, (int)n_iter2)) {
-        snprintf(row, sizeof(row), "k_rowpass_v2<%d,%d> nw=%d grid=%d tail=%d", (n_c + 3) / 4, n_u, (S + 63) / 64,
-                 dmf::rowpass_v2_grid(p->N, S), (int)(p->N & 15));
-        // (one count digit and more than 32 features: the eight-wave form of the integer Gram kernel takes the first 64)
-        snprintf(gram, sizeof(gram), "k_gram_i8<nd=%d>/w8", p->ND);
-    } else if (s->use_fused && n_iter2 <= kSplitInnerSteps) {
-        const int64_t n_full = p->N - (p->N & 15);
-        snprintf(row, sizeof(row), "k_rowpass_fused<%d,%d> nw=%d grid=%d tail=%d", (n_c + 3) / 4, n_u, (S + 63) / 64,
-                 dmf::rowpass_fused_grid(n_full, S), (int)(p->N & 15));
-        snprintf(gram, sizeof(gram), "fused");
-    } else {
-        if (s->use_cm_i8 && s->use_gram_i8 && dmf::u_inner_bu_supported(p->V, S, p->SD, n_u, (int)n_iter2))
-            snprintf(row, sizeof(row), "k_cm_i8<nd=%d>+k_inner_bu", p->ND);
-        else if (s->use_cm_i8) snprintf(row, sizeof(row), "k_cm_i8<nd=%d>+k_u_inner_rows", p->ND);
-        else if (s->use_u_big && dmf::u_phase_big_supported(S, n_c, n_u, (int)n_iter2)) snprintf(row, sizeof(row), "k_u_phase_big");
-        else if (s->u_path == 0 && (n_iter2 > kSplitInnerSteps || n_u >= 7 || (n_c > 0 && n_u >= 5)))
-            snprintf(row, sizeof(row), "k_u_phase_mfma(split)+k_u_inner_rows");
-        else if (s->u_path == 0) snprintf(row, sizeof(row), "k_u_phase_mfma");
-        else if (s->u_path == 1) snprintf(row, sizeof(row), "k_u_phase_gram");
-        else snprintf(row, sizeof(row), "k_u_step_direct");
-        if (s->use_gram_i8 && s->use_cm_i8 && dmf::u_inner_bu_supported(p->V, S, p->SD, n_u, (int)n_iter2))
-            snprintf(gram, sizeof(gram), "k_gram_i8<nd=%d>/w8", p->ND);  // (b_u comes from k_inner_bu)
-        else if (s->use_gram_i8)
-            snprintf(gram, sizeof(gram), "k_bu_cols+k_gram_i8<nd=%d>/w8", p->ND);
-        else snprintf(gram, sizeof(gram), "%s", s->use_gram_spec ? "k_gram_u" : s->use_gram_mfma ? "k_gram_mfma" : "k_gram");
-    }
-    const bool tps = s->ctx->generic_level == 1 || s->ctx->generic_level == 2;
-    const char* alpha = s->purity != nullptr ? (K <= 16 && n_c >= 1 ? "k_alpha_frank_wolfe_row16" : "k_alpha_frank_wolfe")
-                        : (!tps && K <= 16)  ? "k_alpha_phase_row16"
-                        : (!tps && K <= 64)  ? "k_alpha_phase_lanes"
-                        : (tps && K <= 16)   ? "k_alpha_phase"
-                                             : "k_alpha_phase_dyn";
-    snprintf(buf, (size_t)cap, "rowpass=%s gram=%s alpha=%s", row, gram, alpha);
+    if (s == nullptr || buf == nullptr || cap < 1 || n_iter2 < 0) return DMF_ERR_BAD_ARG;
+    const dmf::IterationPlan plan = dmf::plan_iteration(s->key, s->spec, (int)n_iter2, s->purity != nullptr);
+    dmf::describe_plan(s->key, plan, buf, (size_t)cap);
+    return DMF_OK;
+}
+
+int dmf_solver_stop_info(const dmf_solver* s, int* confirm_stops, int64_t* n_confirmed, int64_t* n_unconfirmed,
+                         double* last_stream_cost) {
+    if (s == nullptr) return DMF_ERR_BAD_ARG;
+    if (confirm_stops) *confirm_stops = s->confirm_stops ? 1 : 0;
+    if (n_confirmed) *n_confirmed = s->n_confirmed;
+    if (n_unconfirmed) *n_unconfirmed = s->n_unconfirmed;
+    if (last_stream_cost) *last_stream_cost = s->cf_stream_iter >= 0 ? s->cf_stream : std::nan("");
+    return DMF_OK;
+}
+
+int dmf_select_describe(int64_t N, int64_t S, int64_t n_c, int64_t n_u, int nd, int level, int64_t n_iter2, int flags,
+                        char* buf, int64_t cap) {
+    if (buf == nullptr || cap < 1 || N < 1 || S < 1 || n_c < 0 || n_u < 1 || nd < 0 || nd > 2 || n_iter2 < 0 ||
+        n_c + n_u > dmf::kMaxK)
+        return DMF_ERR_BAD_ARG;
+    dmf::ShapeKey key;
+    key.N = N;
+    key.S = (int)S;
+    key.n_c = (int)n_c;
+    key.n_u = (int)n_u;
+    key.nd = (S <= 2048) ? nd : 0;  // (dmf_problem_create builds no integer copies beyond 2048 samples)
+    key.SD = key.nd > 0 ? (int)((S + 63) / 64 * 64) : 0;
+    key.level = level;
+    key.d_f32_exact = (flags & DMF_SELECT_COUNTS_F32_EXACT) != 0;
+    key.rtp_present = true;
+    key.v_align = (flags & DMF_SELECT_V_UNALIGNED) ? 8 : 0;
+    key.rtp_align = 0;
+    key.alpha_unit = !(flags & DMF_SELECT_ALPHA_OUTSIDE_UNIT);
+    const dmf::PathSpec spec = dmf::select_path(key);
+    if (!spec.supported) return DMF_ERR_UNSUPPORTED;
+    const dmf::IterationPlan plan = dmf::plan_iteration(key, spec, (int)n_iter2, (flags & DMF_SELECT_PURITY) != 0);
+    dmf::describe_plan(key, plan, buf, (size_t)cap);
     return DMF_OK;
 }
 
@@ -1402,7 +1455,7 @@ int dmf_update_u(dmf_context* ctx, const dmf_problem* p, const double* u, const 
         s->h_state->l_w = scalars_io[2];
         st = push_state(s);
     }
-    if (st == DMF_OK) st = enqueue_u_phase(s, (int)n_iter2);
+    if (st == DMF_OK) st = enqueue_u_phase(s, (int)n_iter2, standalone_row_kind(s, (int)n_iter2));
     if (st == DMF_OK) st = export_array(ctx, s->u, un, flags, out_u);
     if (st == DMF_OK) st = export_array(ctx, s->u_prev, un, flags, out_u_prev);
     if (st == DMF_OK) {
@@ -1433,7 +1486,7 @@ int dmf_update_alpha(dmf_context* ctx, const dmf_problem* p, const double* u, in
         s->h_state->l_h = scalars_io[2];
         st = push_state(s);
     }
-    if (st == DMF_OK) st = enqueue_gram(s);
+    if (st == DMF_OK) st = enqueue_gram(s, fp64_gram_kind(s));  // (the caller's u: FP64 kernels)
     if (st == DMF_OK) st = enqueue_alpha_phase(s, (int)n_iter2);
     if (st == DMF_OK) st = export_array(ctx, s->alpha, an, flags, out_alpha);
     if (st == DMF_OK) st = export_array(ctx, s->alpha_prev, an, flags, out_alpha_prev);

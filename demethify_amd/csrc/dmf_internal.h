@@ -22,7 +22,8 @@ struct SolverState {
     double cf_prev;    // cf_0 (:207)
     double tol;        // stop threshold of the running step() call (:220)
     long long iters;   // outer iterations completed
-    int done;          // 1 once |cf - cf_0| < tol was met; later launches are no-ops
+    double band;       // 1: |cf - cf_0| < tol stops; > 1: |cf - cf_0| < band x tol pauses for the host's confirmation
+    int done;          // 1 once |cf - cf_0| < tol was met, 2 while paused: later launches are no-ops
     int arrive;        // workgroups of the alpha kernel that have finished this outer iteration (the last one closes it)
 };
 

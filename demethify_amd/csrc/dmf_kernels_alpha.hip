@@ -278,7 +278,8 @@ __device__ __forceinline__ void finish_iteration_body(const double* __restrict__
         state->cf = cost;
         state->iters += 1;
         state->arrive = 0;
-        if (fabs(cost - cf_prev) < state->tol) state->done = 1;
+        // deconvolution.py:220.  (A NaN cf_0 -- no cost before the loop was asked for -- compares false.)
+        if (fabs(cost - cf_prev) < state->tol * state->band) state->done = state->band > 1.0 ? 2 : 1;
     }
 }
 
@@ -845,8 +846,10 @@ __global__ __launch_bounds__(256) void k_init_state(SolverState* __restrict__ st
         state->l_w_prev = state->l_w;
         state->l_h = (rt2 + state->u_norm2) * dsq;
         state->l_h_prev = state->l_h;
+        state->cf = __longlong_as_double(0x7FF8000000000000ll);  // not computed yet (dmf_solver_step, dmf_solver_get)
         state->cf_prev = state->cf;
         state->tol = 0.0;
+        state->band = 1.0;
         state->iters = 0;
         state->done = 0;
         state->arrive = 0;

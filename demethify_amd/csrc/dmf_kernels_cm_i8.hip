@@ -378,7 +378,9 @@ static hipError_t launch_cm_t(const double* V, const unsigned short* D16, int SD
     const int64_t want = (nblk + kCmWaves - 1) / kCmWaves;
     // one workgroup (two waves per SIMD at ~200 registers) per CU, two where the tables leave room
     int per_cu = lds <= 76 * 1024 ? 2 : 1;
+#ifdef DMF_EXPERIMENT  // (an experiment build only: DMF_EXPERIMENT=1 python -m demethify_amd._build)
     if (const char* v = getenv("DMF_CM_PER_CU")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (experiments)
+#endif
     const int64_t cap = (int64_t)256 * per_cu;
     const int64_t grid = want < cap ? want : cap;
     hipLaunchKernelGGL((k_cm_i8<NKC, ND, NCGX, S4>), dim3((unsigned)grid), dim3(kCmWaves * 64), lds, st, V, D16, SD, Rtp, alpha,

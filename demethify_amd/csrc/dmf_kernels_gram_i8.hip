@@ -739,9 +739,13 @@ __global__ __launch_bounds__(256) void k_gram_v2_reduce(const long long* __restr
     __syncthreads();
     if (threadIdx.x == 0) {
         int* __restrict__ cnt = arrive + (int64_t)job * gridDim.x + blockIdx.x;
-        const int old = atomicAdd(cnt, 1);
+        // The arrival is an agent-scope acquire-release operation: this workgroup's contributions (performed, see above)
+        // are ordered before it, and the finishing workgroup's collecting exchanges behind it, by the memory model and
+        // not only by how gfx950 happens to perform atomics.  One lane per workgroup pays for it (not every wave).
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = old == (int)gridDim.z - 1;
-        if (last_flag) *cnt = 0;  // ready for the next outer iteration (nobody else touches it any more)
+        // ready for the next outer iteration (nobody else touches it any more in this launch)
+        if (last_flag) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!last_flag || grp != 0 || !active) return;

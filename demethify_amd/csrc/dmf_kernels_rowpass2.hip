@@ -617,7 +617,9 @@ bool rowpass_v2_supported(int S, int n_c, int n_u, int n_iter2) {
 int rowpass_v2_grid(int64_t N, int S) {
     const int NW = (S + 63) / 64;
     int per_cu = NW > 4 ? 1 : 8 / NW;  // two waves per SIMD: NW = 5..8 -> 1, 4 -> 2, 3 -> 2, 2 -> 4, 1 -> 8 workgroups per CU
+#ifdef DMF_EXPERIMENT  // (an experiment build only: DMF_EXPERIMENT=1 python -m demethify_amd._build)
     if (const char* v = getenv("DMF_V2_PER_CU")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (experiments)
+#endif
     const int64_t nblk = (N + 15) / 16;
     const int64_t g = 256 * per_cu;
     return (int)(nblk < g ? nblk : g);

@@ -289,7 +289,9 @@ static hipError_t launch_big_t(const double* V, const double* D, const double* R
     }
     const int64_t nblk = (N + 15) / 16;
     int per_cu = lds <= 78 * 1024 ? 2 : 1;
+#ifdef DMF_EXPERIMENT  // (an experiment build only: DMF_EXPERIMENT=1 python -m demethify_amd._build)
     if (const char* v = getenv("DMF_UBIG_PER_CU")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (experiments)
+#endif
     const int64_t want = 256 * per_cu;
     const int64_t grid = nblk < want ? nblk : want;
     hipLaunchKernelGGL((k_u_phase_big<NKC, GS>), dim3((unsigned)grid), dim3(GS == 16 ? 256 : 512), lds, st, V, D, Rtp,

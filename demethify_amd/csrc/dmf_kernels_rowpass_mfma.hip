@@ -333,7 +333,9 @@ static hipError_t launch_u_mfma_t(const double* V, const double* D, const unsign
     // persistent workgroups: as many as fit two waves per SIMD (the kernel needs ~250 registers) -- 3 per CU at
     // NW = 2 left a quarter of the wave slots empty
     int per_cu = NW >= 8 ? 1 : 8 / NW;
+#ifdef DMF_EXPERIMENT  // (an experiment build only: DMF_EXPERIMENT=1 python -m demethify_amd._build)
     if (const char* v = getenv("DMF_UMFMA_PER_CU")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (experiments)
+#endif
     const int64_t cap = (int64_t)256 * per_cu;
     const int64_t grid = nblk < cap ? nblk : cap;
     if (d16)

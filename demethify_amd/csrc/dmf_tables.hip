@@ -155,6 +155,13 @@ inline bool field(const Line& ln, char sep, int index, const char** fb, const ch
     return true;
 }
 
+// fields of a line (separators + 1)
+inline int count_fields(const Line& ln, char sep) {
+    int n = 1;
+    for (const char* p = ln.b; (p = (const char*)memchr(p, sep, (size_t)(ln.e - p))) != nullptr; ++p) ++n;
+    return n;
+}
+
 }  // namespace
 
 extern "C" {
@@ -186,6 +193,10 @@ int dmf_table_scan(const char* path, char sep, int64_t* n_rows, int* col_percent
         Line ln;
         p = next_line(p, end, &ln);
         if (ln.e == ln.b) return DMF_ERR_UNSUPPORTED;  // blank lines: pandas skips them, keep that logic in one place
+        // A data row with another field count than the header: pandas has rules of its own for that (one extra field in
+        // every row -- a trailing separator -- makes the first column an implicit index and shifts the names; short rows
+        // are filled with NaN).  Checked on the first row here and on every row by dmf_table_read.
+        if (rows == 0 && count_fields(ln, sep) != *n_cols) return DMF_ERR_UNSUPPORTED;
         ++rows;
     }
     *n_rows = rows;
@@ -203,6 +214,7 @@ int dmf_table_read(const char* path, char sep, int col_percent_modified, int col
     const char* end = m.p + m.n;
     Line hdr;
     const char* body = next_line(m.p, end, &hdr);
+    const int n_cols = count_fields(hdr, sep);
     if (n_threads < 1) n_threads = 1;
     if ((size_t)(end - body) < (size_t)n_threads * 65536) n_threads = 1;
     // chunk boundaries at line starts
@@ -244,7 +256,8 @@ int dmf_table_read(const char* path, char sep, int col_percent_modified, int col
                 const char *fb, *fe;
                 double x;
                 bool is_int;
-                if (!field(ln, sep, col_percent_modified, &fb, &fe) || !parse_number(fb, fe, &x, &is_int)) {
+                if (count_fields(ln, sep) != n_cols ||  // (ragged rows: pandas' rules, see dmf_table_scan)
+                    !field(ln, sep, col_percent_modified, &fb, &fe) || !parse_number(fb, fe, &x, &is_int)) {
                     status = DMF_ERR_UNSUPPORTED;
                     return;
                 }

@@ -284,6 +284,8 @@ class Solver:
                                      "(staging.DeviceArray / contiguous CUDA tensors) on the context's GPU")
             u0 = u0.reshape(problem.N, -1)
             flags = L.DMF_PTR_DEVICE
+            if getattr(alpha0, "in_unit_range", None) is True:  # (checked on the host by the thread that uploaded it)
+                flags |= L.DMF_INIT_IN_UNIT_RANGE
         else:
             u0 = np.ascontiguousarray(u0, dtype=np.float64).reshape(problem.N, -1)
             alpha0 = np.ascontiguousarray(alpha0, dtype=np.float64)
@@ -332,6 +334,16 @@ class Solver:
         buf = C.create_string_buffer(512)
         L.check(self._lib.dmf_solver_describe(self._h, int(n_iter2), buf, len(buf)), "dmf_solver_describe")
         return buf.value.decode()
+
+    def stop_info(self):
+        """How the stop tests of this solver's step() calls were decided (dmf_solver_stop_info): a dict with
+        confirm_stops (streaming-cost confirmation active for the last step() call), n_confirmed, n_unconfirmed and
+        last_stream_cost (NaN: none taken)."""
+        on, nc, nu, cs = C.c_int(), C.c_int64(), C.c_int64(), C.c_double()
+        L.check(self._lib.dmf_solver_stop_info(self._h, C.byref(on), C.byref(nc), C.byref(nu), C.byref(cs)),
+                "dmf_solver_stop_info")
+        return {"confirm_stops": bool(on.value), "n_confirmed": nc.value, "n_unconfirmed": nu.value,
+                "last_stream_cost": cs.value}
 
     def get_alpha(self):
         """The current proportions (K x S) as a fresh host array; u stays on the device."""

@@ -106,7 +106,8 @@ def evaluate_best_ic(meth_f, ref, counts, init_option, ic, seed, iter1, iter2, t
     ``n_u_values`` defaults to upstream's hard-coded ``range(1, 26)`` (ic.py:171).  AIC / BIC sweeps
     are sharded across the ranks of an initialised torch.distributed job; CCC and BCV run serially.
     """
-    if n_u_values is None:
+    default_range = n_u_values is None
+    if default_range:
         n_u_values = range(1, 25 + 1)
     n_u_values = list(n_u_values)
     n_cpg, n_samples = meth_f.shape
@@ -138,8 +139,21 @@ def evaluate_best_ic(meth_f, ref, counts, init_option, ic, seed, iter1, iter2, t
 
     # AIC / BIC: one solve per candidate; candidates dealt to ranks longest-first (cost grows with n_u)
     rank, world, _ = shard.dist_state()
-    too_many = [n for n in n_u_values if n_ct + n > L.MAX_K or n < 1]
-    if too_many:  # checked on every rank before any solve, so that all ranks fail together
+    # (checked on every rank before any solve, so that all ranks fail -- or trim -- together)
+    not_positive = [n for n in n_u_values if n < 1]
+    if not_positive:
+        raise ValueError(f"candidate n_u values {not_positive}: a number of unknown cell types is at least 1")
+    too_many = [n for n in n_u_values if n_ct + n > L.MAX_K]
+    if too_many and default_range:
+        # upstream's hard-coded 1..25 (ic.py:171) with a reference matrix of 40 or more known types: the kernels take
+        # L.MAX_K cell types in total, so the sweep ends where they do -- a deliberate difference, said out loud
+        n_u_values = [n for n in n_u_values if n_ct + n <= L.MAX_K]
+        if rank == 0:
+            print(f"note: with {n_ct} known cell types the sweep stops at {L.MAX_K - n_ct} unknown ones "
+                  f"({L.MAX_K} cell types in total is what the kernels are built for; upstream would go on to 25)")
+        if not n_u_values:
+            raise ValueError(f"{n_ct} known cell types leave no room for an unknown one ({L.MAX_K} in total at most)")
+    elif too_many:
         raise ValueError(f"candidate n_u values {too_many} need more than {L.MAX_K} cell types in total "
                          f"({n_ct} known): outside what the kernels are built for")
     order = sorted(range(len(n_u_values)), key=lambda i: -n_u_values[i])

@@ -74,6 +74,9 @@ class DeviceArray:
 
         self.ctx, self._ptr, self.shape = ctx, ptr, tuple(int(x) for x in shape)
         self._fin = weakref.finalize(self, _release, ctx, ptr)
+        # every value inside [0, 1]?  (to_device looks at small arrays -- the proportions -- on the uploading thread, so
+        # that dmf_solver_create need not bring alpha0 back to the host for it: DMF_INIT_IN_UNIT_RANGE)
+        self.in_unit_range = None
 
     def data_ptr(self) -> int:
         return self._ptr
@@ -86,6 +89,7 @@ class DeviceArray:
             raise ValueError(f"cannot reshape {self.shape} to {shape}")
         view = DeviceArray.__new__(DeviceArray)
         view.ctx, view._ptr, view.shape, view._fin, view._base = self.ctx, self._ptr, shape, None, self
+        view.in_unit_range = self.in_unit_range
         return view
 
     def close(self):
@@ -119,6 +123,8 @@ def to_device(arrays, ctx):
         finally:
             _give_back(buf)
         out.append(DeviceArray(ctx, dev.value, a.shape))
+        if a.size <= (1 << 20):
+            out[-1].in_unit_range = bool(a.size == 0 or (a.min() >= 0.0 and a.max() <= 1.0))
     return out
 
 

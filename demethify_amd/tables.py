@@ -70,6 +70,11 @@ def _read_one(job):
     return read_sample(*job)
 
 
+# Set once this process has asked the library for page-locked memory (dmf_host_alloc brings up the HIP runtime: its
+# threads, its locks, the KFD file descriptor): from then on no worker PROCESS is forked here any more.
+_hip_runtime_up = False
+
+
 def _read_many(paths, bedmethyl, fillna):
     if not paths:
         return []
@@ -77,6 +82,13 @@ def _read_many(paths, bedmethyl, fillna):
     jobs = [(p, bedmethyl, fillna) for p in paths]
     if workers == 1:
         return [_read_one(j) for j in jobs]
+    if _hip_runtime_up:
+        # the native reader declined a file AFTER it had allocated its page-locked matrices (an NA in mid-file, a
+        # fractional coverage): threads instead of forked processes (pandas' C parser releases the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            return list(pool.map(_read_one, jobs))
     # fork, not spawn: the workers only parse text and hand two arrays back; they never touch the GPU runtime,
     # and no new program is exec'ed from a process that may already hold a device
     with ProcessPoolExecutor(max_workers=workers, mp_context=multiprocessing.get_context("fork")) as pool:
@@ -103,6 +115,9 @@ def _host_matrix(shape, dtype):
     lib = L.load()
     n_bytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
     pinned = C.c_int(0)
+    global _hip_runtime_up
+    if n_bytes:
+        _hip_runtime_up = True  # (whether or not the allocation ends up page-locked: the library has asked the runtime)
     ptr = lib.dmf_host_alloc(n_bytes, C.byref(pinned)) if n_bytes else None
     if not ptr:
         return np.empty(shape, dtype=dtype)

@@ -41,7 +41,18 @@ typedef enum dmf_status {
 
 enum {
     DMF_PTR_DEVICE = 1,       /* data pointers of this call are device pointers                  */
-    DMF_COUNTS_F64 = 2        /* `counts` is float64 (default: int64, as pandas yields)          */
+    DMF_COUNTS_F64 = 2,       /* `counts` is float64 (default: int64, as pandas yields)          */
+    DMF_INIT_IN_UNIT_RANGE = 4 /* dmf_solver_create: the caller vouches that alpha0 lies inside [0, 1] (columns on the
+                                * simplex: every initialiser of deconvolution.py:40-78 and :108-137 yields that), so the
+                                * library skips its own check -- a device-to-host round trip for device arrays */
+};
+
+/* dmf_select_describe flags */
+enum {
+    DMF_SELECT_COUNTS_F32_EXACT = 1,   /* every count survives a round trip through f32                  */
+    DMF_SELECT_PURITY = 2,             /* a purity vector is set (Frank-Wolfe alpha phase)               */
+    DMF_SELECT_ALPHA_OUTSIDE_UNIT = 4, /* the starting alpha does not lie inside [0, 1]                  */
+    DMF_SELECT_V_UNALIGNED = 8         /* meth_frequency starts 8 bytes off a 16-byte boundary           */
 };
 
 /* solver variants */
@@ -154,6 +165,20 @@ int dmf_solver_destroy(dmf_solver* s);
  * parity case asserts the path it means to cover) and for bench.py's kernel label.  buf gets at most cap bytes
  * including the terminator. */
 int dmf_solver_describe(const dmf_solver* s, int64_t n_iter2, char* buf, int64_t cap);
+/* The same text for a shape that need not exist on a device: the kernel-selection table itself (csrc/dmf_select.hip),
+ * a pure function of (N, S, n_c, n_u, count digit planes nd = 0 | 1 | 2, kernel level, n_iter2, DMF_SELECT_* flags).
+ * No GPU is touched: tests/test_host.py enumerates a grid of shapes against tests/golden/kernel_selection.tsv.
+ * DMF_ERR_UNSUPPORTED where no kernel takes the shape. */
+int dmf_select_describe(int64_t N, int64_t S, int64_t n_c, int64_t n_u, int nd, int level, int64_t n_iter2, int flags,
+                        char* buf, int64_t cap);
+/* How the stop test |cf - cf_0| < tol (deconvolution.py:218-220) of this solver's dmf_solver_step calls was decided.
+ * The loop's cost is the Gram form v^T D v - 2 a.b + a^T G a; where its error bound (it grows with N S max(counts)) is
+ * not far below tol, an iteration whose Gram-form difference falls below 10 tol is decided on the STREAMING cost of
+ * deconvolution.py:15-17 for this and the previous iterate (confirm_stops = 1; n_confirmed such decisions so far,
+ * n_unconfirmed decisions inside that band that had only the Gram form -- the first iteration to enter it);
+ * last_stream_cost = the latest streaming cost taken for a stop test (NaN: none).  Any pointer may be NULL. */
+int dmf_solver_stop_info(const dmf_solver* s, int* confirm_stops, int64_t* n_confirmed, int64_t* n_unconfirmed,
+                         double* last_stream_cost);
 /* One-shot convenience: create + step(n_iter1) + get + destroy. */
 int dmf_solve(dmf_context* ctx, const dmf_problem* p, const double* u0, const double* alpha0,
               int64_t n_u, int mode, int64_t n_iter1, int64_t n_iter2, double tol, int flags,

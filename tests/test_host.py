@@ -168,6 +168,17 @@ def test_native_table_reader_is_bit_identical_to_pandas(tmp_path):
     quoted = tmp_path / "q.csv"
     quoted.write_text('valid_coverage,percent_modified\n3,"0.5"\n')
     assert tables.read_samples_native([str(quoted)], False) is None
+    # rows with another field count than the header: a trailing separator in every row makes pandas shift the names (an
+    # implicit index column), a short row gets NaN -- both are left to pandas, wherever in the file they occur
+    trailing = tmp_path / "trailing.bed"
+    trailing.write_text("chrom\tvalid_coverage\tpercent_modified\nchr1\t2\t5.0\t\nchr1\t3\t6.0\t\n")
+    assert tables.read_samples_native([str(trailing)], True) is None
+    late = tmp_path / "late.bed"
+    late.write_text("chrom\tvalid_coverage\tpercent_modified\n" + "chr1\t2\t5.0\n" * 50 + "chr1\t3\t6.0\t7\n" + "chr1\t2\t5.0\n" * 5)
+    assert tables.read_samples_native([str(late)], True) is None
+    short = tmp_path / "short.csv"
+    short.write_text("valid_coverage,other,percent_modified\n3,1,0.5\n4,0.25\n")
+    assert tables.read_samples_native([str(short)], False) is None
     # a single-column csv gets coverage 1 (demethify.py:137-138)
     single = tmp_path / "single.csv"
     single.write_text("percent_modified\n0.5\n0.125\n")
@@ -286,3 +297,47 @@ def test_prefetcher_with_several_workers_keeps_item_order():
             seen.append(k)
     assert seen == list(range(9))
     pf.close()
+
+
+def test_kernel_selection_table():
+    """Kernel selection is one pure function (csrc/dmf_select.hip): its answers for a grid of shapes, levels, count
+    encodings, inner-step counts and flags are pinned by a checked-in table (no GPU involved)."""
+    import importlib.util
+
+    from demethify_amd import _lib as L
+
+    spec = importlib.util.spec_from_file_location("make_kernel_selection", ROOT / "tests" / "golden" / "make_kernel_selection.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lib = L.load()
+    want = [line.rstrip("\n").split("\t") for line in (ROOT / "tests" / "golden" / "kernel_selection.tsv").read_text().splitlines()
+            if not line.startswith("#")]
+    rows = list(mod.grid())
+    assert len(rows) == len(want)
+    for row, w in zip(rows, want):
+        assert [str(x) for x in row] == w[:8]
+        assert mod.describe(lib, row) == w[8], row
+    # a few rows a reader can check against DESIGN.md section 5 by eye
+    table = {tuple(int(x) for x in w[:8]): w[8] for w in want}
+    f32 = L.DMF_SELECT_COUNTS_F32_EXACT
+    assert table[(1000000, 256, 12, 4, 1, 0, 20, f32)].startswith("rowpass=k_rowpass_v2<3,4> nw=4 grid=512")
+    assert "k_rowpass_fused<3,4>" in table[(1000000, 256, 12, 4, 0, 0, 20, f32)]        # counts without integer copies
+    assert "k_rowpass_fused<3,4>" in table[(1000000, 256, 12, 4, 1, 0, 0, f32)]         # no inner step: u is not clipped
+    assert "k_cm_i8<nd=1>+k_inner_bu" in table[(1000000, 127, 0, 8, 1, 0, 20, f32)]
+    assert "k_u_phase_mfma(split)" in table[(1000000, 256, 12, 4, 1, 0, 500, f32)]      # --purity's 500 inner steps
+    assert "k_rowpass_v2" not in table[(1000000, 256, 12, 4, 1, 0, 20, f32 | L.DMF_SELECT_ALPHA_OUTSIDE_UNIT)]
+    assert "alpha=k_alpha_frank_wolfe_row16" in table[(1000000, 256, 12, 4, 1, 0, 20, f32 | L.DMF_SELECT_PURITY)]
+
+
+def test_ic_sweep_range_checks_come_before_any_gpu_work():
+    """evaluate_best_ic: a candidate below 1 and an EXPLICIT candidate beyond the kernels' 64 cell types raise (with their
+    own messages) before a device is touched; only upstream's default 1..25 is trimmed to what fits (GPU test)."""
+    from demethify_amd.ic import evaluate_best_ic
+
+    V = np.full((20, 3), 0.5)
+    D = np.full((20, 3), 7, dtype=np.int64)
+    ref = np.full((20, 40), 0.5)
+    with pytest.raises(ValueError, match="at least 1"):
+        evaluate_best_ic(V, ref, D, "uniform_", "BIC", 1, 2, 2, 0.0, n_u_values=[0, 2])
+    with pytest.raises(ValueError, match="more than 64 cell types"):
+        evaluate_best_ic(V, ref, D, "uniform_", "BIC", 1, 2, 2, 0.0, n_u_values=[2, 30])
