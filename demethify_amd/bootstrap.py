@@ -53,10 +53,11 @@ def _device_stack(n_local, width):
 
 
 def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, n_iter1, n_iter2, tol, header,
-          outdir, samples, purity, seed, materialize=True):
+          outdir, samples, purity, seed, materialize=True, _observe=None):
     """bootstrap.py:10-93 -> [proportions CI DataFrame, (profile CI DataFrame)]; writes the two CSVs.
     materialize=False (the CLI, which ignores the return value) skips building the N-row DataFrame of tuples for the
-    profile intervals: the CSV is written by the library and the second result is the (lower, upper) array pair."""
+    profile intervals: the CSV is written by the library and the second result is the (lower, upper) array pair.
+    _observe(i, seed_i, row_indices, solver) is called after replicate i's solve (tests look at the replicate through it)."""
     purity_frac = None
     if purity:
         # upstream quirk kept: bt_ci takes the raw percentages and uses p / 100 (bootstrap.py:18) while main()
@@ -126,6 +127,8 @@ def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, 
                         if purity_frac is not None:
                             s.set_purity(purity_frac)
                         s.step(n_iter1, n_iter2, tol)
+                        if _observe is not None:
+                            _observe(i, seeds[i], idx, s)
                         if u_stack is not None:
                             s.copy_u_to(u_stack[j])
                             local.append((i, (None, s.get_alpha())))

@@ -75,6 +75,11 @@ class Context:
         MFMA row pass + one-pass Gram pair, 4 the first-generation fused FP64 row pass.  Set before creating Problems."""
         L.check(self._lib.dmf_context_set_generic(self._h, int(level)), "dmf_context_set_generic")
 
+    def set_stop_confirmation(self, mode: int):
+        """How step() decides |cf - cf_0| < tol: 0 (default) Gram-form cost, confirmed on the streaming cost where the
+        Gram form's error bound reaches tol / 20; 1 always on streaming costs near the threshold; 2 Gram form only."""
+        L.check(self._lib.dmf_context_set_stop_confirmation(self._h, int(mode)), "dmf_context_set_stop_confirmation")
+
     def reset_kernel_time(self):
         L.check(self._lib.dmf_context_reset_kernel_time(self._h), "dmf_context_reset_kernel_time")
 

@@ -96,6 +96,12 @@ int dmf_context_reset_kernel_time(dmf_context* ctx);
  * Gram), 4 = the first-generation fused FP64 row pass (level 0's fall-back for counts beyond 32639 or reference
  * profiles outside [0, 1]).  Set it before creating problems: the integer count copies are built at level 0 only. */
 int dmf_context_set_generic(dmf_context* ctx, int level);
+/* How dmf_solver_step decides |cf - cf_0| < tol (deconvolution.py:218-220) for the solvers of this context:
+ * 0 (default) = on the Gram-form cost of the loop, with the decisions near the threshold confirmed on the streaming
+ * cost of deconvolution.py:15-17 where the Gram form's error bound (1e-15 N S max(counts)) reaches tol / 20;
+ * 1 = every decision near the threshold (below 10 tol) is taken on streaming costs, whatever the bound;
+ * 2 = Gram form only.  See dmf_solver_stop_info. */
+int dmf_context_set_stop_confirmation(dmf_context* ctx, int mode);
 
 /* ---- problem: V, D, Rt resident in HBM + the per-problem constants ----------------------
  * Replaces the (meth_frequency, d_x, R_trunc) argument triple every reference solver call

@@ -139,3 +139,66 @@ def test_bootstrap_building_blocks_at_headline_size(ctx):
     cols = np.r_[0:1000, 499_000:500_000, 999_000:1_000_000]
     want_q = np.percentile(x[:, torch.from_numpy(cols).to(dev)].cpu().numpy(), q, axis=0)
     assert np.array_equal(got[:, torch.from_numpy(cols).to(dev)].cpu().numpy(), want_q)  # numpy's "linear" method, bit for bit
+
+
+def test_config4_bootstrap_end_to_end_at_headline_size(ctx, tmp_path):
+    """BASELINE.json configs[3] through the driver itself (demethify_amd.bootstrap.bt_ci = bootstrap.py:10-93) at
+    1e6 CpG x 256 samples, 12 + 4: 8 replicates of 5 outer iterations.  The oracle cannot run a 1e6-row replicate in
+    test time, so what is asserted needs no oracle solve: the replicates' seeds and row draws are the oracle's
+    (bootstrap.py:27-28), every replicate's loop cost agrees with the streaming cost of its iterate, the bounds are
+    ordered, and the two CSV files parse back to the percentile arrays bit for bit (bootstrap.py:70,89)."""
+    import re
+    import zlib
+
+    import pandas as pd
+
+    torch = pytest.importorskip("torch")
+    from bench import make_inputs_on_device
+    from demethify_amd.bootstrap import bt_ci
+
+    N, S, n_c, n_u, B = 1_000_000, 256, 12, 4, 8
+    Vd, Dd, Rd = make_inputs_on_device(torch, torch.device("cuda", 0), N, S, n_c, n_u, seed=0)
+    V, D, Rt = Vd.cpu().numpy(), Dd.cpu().numpy().astype(np.int64), Rd.cpu().numpy()
+    del Vd, Dd, Rd
+    header = [f"type_{k}" for k in range(n_c)]
+    samples = [f"s{k}" for k in range(S)]
+    seen = {}
+
+    def observe(i, seed_i, idx, solver):
+        seen[i] = (seed_i, zlib.crc32(np.ascontiguousarray(idx).tobytes()), solver.get_cost(), solver.direct_cost())
+
+    res = bt_ci(95, B, n_u, V, D, Rt, "uniform_", 5, 20, 0.0, header, str(tmp_path), samples, None, 1,
+                materialize=False, _observe=observe)
+    seeds = osol.bootstrap_seeds(1, B)
+    assert sorted(seen) == list(range(B))
+    for i in range(B):
+        seed_i, crc, (gram_cost, iters), stream_cost = seen[i]
+        assert seed_i == seeds[i] and iters == 5
+        assert crc == zlib.crc32(osol.bootstrap_indices(seeds[i], N).tobytes())
+        assert abs(gram_cost - stream_cost) < 1e-3 and stream_cost > 0
+    props_df, (lower_u, upper_u) = res
+    assert lower_u.shape == upper_u.shape == (N, n_u) and (lower_u <= upper_u).all()
+    assert (lower_u >= 0).all() and (upper_u <= 1).all() and (upper_u > lower_u).mean() > 0.9
+    lo_p = np.array([[props_df.iloc[k, i][0] for i in range(S)] for k in range(n_c + n_u)])
+    hi_p = np.array([[props_df.iloc[k, i][1] for i in range(S)] for k in range(n_c + n_u)])
+    assert (lo_p <= hi_p).all() and (lo_p >= 0).all() and (hi_p <= 1).all() and (hi_p > lo_p).any()
+
+    number = r"(?:np\.float64\()?([-+0-9.eEinfa]+)\)?"
+    pair = re.compile(r"\(" + number + ", " + number + r"\)")
+
+    def parse(frame):
+        lo = np.empty(frame.shape)
+        hi = np.empty(frame.shape)
+        for c, col in enumerate(frame.columns):
+            both = frame[col].str.extract(pair).astype(np.float64).to_numpy()
+            lo[:, c], hi[:, c] = both[:, 0], both[:, 1]
+        return lo, hi
+
+    est = pd.read_csv(tmp_path / "confidence_interval_methylation_estimate.csv")
+    assert list(est.columns) == [f"unknown_cell_{k + 1}" for k in range(n_u)] and len(est) == N
+    lo, hi = parse(est)
+    assert np.array_equal(lo, lower_u) and np.array_equal(hi, upper_u)  # repr round trip: bit for bit
+    prop = pd.read_csv(tmp_path / "confidence_interval_celltypes_proportions.csv", index_col=0)
+    assert list(prop.index) == header + [f"unknown_cell_{k + 1}" for k in range(n_u)] and list(prop.columns) == samples
+    lo, hi = parse(prop)
+    assert np.array_equal(lo, lo_p) and np.array_equal(hi, hi_p)
