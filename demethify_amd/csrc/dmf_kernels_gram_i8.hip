@@ -633,23 +633,19 @@ hipError_t launch_bu_cols(const double* V, const unsigned short* D16, int SD, co
 // ------------------------------------------------------------------------------------------------ reduce
 constexpr int kRedChunks = 16;
 
-// One launch: grid (sample blocks, jobs, kRedChunks).  Jobs < n_feat add their chunk of the i64 slabs into acc64 with
-// 64-bit integer atomics (exact, so the order does not matter); the b_u jobs store their chunk's sum (slab order) into
-// bu_part.  The LAST of a (sample block, job)'s kRedChunks workgroups to arrive -- a counter per column of the grid,
-// reset by that workgroup -- turns the complete sums into the solver's packed Gram rows (atomicExch reads and clears
-// acc64 for the next outer iteration; bu_part is summed in chunk order): the finishing pass is not a launch of its own.
+// Grid (sample blocks, jobs, kRedChunks).  Jobs < n_feat add their chunk of the i64 slabs into acc64 with 64-bit integer
+// atomics (exact, so the order does not matter); the b_u jobs store their chunk's sum (slab order) into bu_part;
+// k_gram_v2_finish turns the complete sums into the solver's packed Gram rows.
 // Loads are issued four slabs ahead of their use (the loop is a chain of HBM round trips otherwise).
 __global__ __launch_bounds__(256) void k_gram_v2_reduce(const long long* __restrict__ slab_i8, int ny, int MF, int SDs,
                                                         const double* __restrict__ slab_bu, int n_bu_slabs, int n_u,
                                                         int n_feat, int S, unsigned long long* __restrict__ acc64,
-                                                        double* __restrict__ bu_part, int* __restrict__ arrive,
-                                                        const int* __restrict__ dst_row, double* __restrict__ gb,
+                                                        double* __restrict__ bu_part,
                                                         const int* __restrict__ done_flag,
                                                         const double* __restrict__ u2_partials, int n_u2,
                                                         SolverState* __restrict__ state) {
     __shared__ long long part[3][2][64];
     __shared__ double partd[3][64];
-    __shared__ int last_flag;
     if (done_flag != nullptr && *done_flag) return;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int s = blockIdx.x * 64 + lane;
@@ -697,10 +693,8 @@ __global__ __launch_bounds__(256) void k_gram_v2_reduce(const long long* __restr
         if (grp == 0 && active && y0 < y1) {
             lo += part[0][0][lane] + part[1][0][lane] + part[2][0][lane];
             hi += part[0][1][lane] + part[1][1][lane] + part[2][1][lane];
-            // (returning atomics, the returns consumed: see the hand-over below)
-            const unsigned long long r0 = atomicAdd(acc64 + (int64_t)job * S + s, (unsigned long long)lo);
-            const unsigned long long r1 = atomicAdd(acc64 + ((int64_t)n_feat + job) * S + s, (unsigned long long)hi);
-            asm volatile("" ::"v"(r0), "v"(r1));
+            atomicAdd(acc64 + (int64_t)job * S + s, (unsigned long long)lo);
+            atomicAdd(acc64 + ((int64_t)n_feat + job) * S + s, (unsigned long long)hi);
         }
     } else {
         const int j = job - n_feat;
@@ -721,45 +715,36 @@ __global__ __launch_bounds__(256) void k_gram_v2_reduce(const long long* __restr
         }
         if (grp > 0) partd[grp - 1][lane] = acc;
         __syncthreads();
-        if (grp == 0 && active) {  // (handed over as a returning atomic exchange, like the integer sums: see below)
-            const double v = ((acc + partd[0][lane]) + partd[1][lane]) + partd[2][lane];
-            const unsigned long long r = atomicExch(reinterpret_cast<unsigned long long*>(bu_part) + ((int64_t)chunk * n_u + j) * S + s,
-                                                    (unsigned long long)__double_as_longlong(v));
-            asm volatile("" ::"v"(r));
-        }
+        if (grp == 0 && active) bu_part[((int64_t)chunk * n_u + j) * S + s] = ((acc + partd[0][lane]) + partd[1][lane]) + partd[2][lane];
     }
-    // ---- the last workgroup of this (sample block, job) finishes it.  The hand-over uses atomics only: every value a
-    // workgroup contributes goes out as a RETURNING atomic (add / exchange) whose return is awaited (__syncthreads()
-    // drains vmcnt) before the workgroup's arrival is counted, and the finishing workgroup -- the one whose own counter
-    // atomic returned gridDim.z - 1 -- collects with atomic exchanges.  All atomics on an address are performed in one
-    // place, and a returned value means "performed", so the last arrival sees every contribution.  (An agent-scope
-    // __threadfence() instead made every wave write back its XCD's L2: +0.29 ms per launch at the headline shape.
-    // No-return atomics are acknowledged before they are performed: with them the finishing workgroup now and then
-    // missed a chunk, which tests/test_gpu_bench_paths.py caught as a 1e-5 error in one run out of three.)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int* __restrict__ cnt = arrive + (int64_t)job * gridDim.x + blockIdx.x;
-        // The arrival is an agent-scope acquire-release operation: this workgroup's contributions (performed, see above)
-        // are ordered before it, and the finishing workgroup's collecting exchanges behind it, by the memory model and
-        // not only by how gfx950 happens to perform atomics.  One lane per workgroup pays for it (not every wave).
-        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last_flag = old == (int)gridDim.z - 1;
-        // ready for the next outer iteration (nobody else touches it any more in this launch)
-        if (last_flag) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!last_flag || grp != 0 || !active) return;
+}
+
+// The finishing pass: the complete sums -> the solver's packed Gram rows, and the scratch cleared for the next outer
+// iteration.  A launch of its own: the kernel boundary is what orders every workgroup's contributions before these reads.
+// (Round 2 let the last workgroup of a column to arrive do this inside k_gram_v2_reduce, on relaxed atomics -- 3 us
+// cheaper per outer iteration, and correct on gfx950 in every test, but resting on "a returned atomic has been
+// performed", which the memory model does not promise.  Making the arrival an agent-scope acquire-release operation
+// instead costs +85 us per launch at the headline shape: the release writes back an L2 that the integer Gram kernel has
+// just filled with 34 MB of slabs.)
+__global__ __launch_bounds__(64) void k_gram_v2_finish(int n_u, int n_feat, int S, unsigned long long* __restrict__ acc64,
+                                                       double* __restrict__ bu_part, const int* __restrict__ dst_row,
+                                                       double* __restrict__ gb, const int* __restrict__ done_flag) {
+    if (done_flag != nullptr && *done_flag) return;
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    const int job = blockIdx.y;
+    if (s >= S) return;
     if (job < n_feat) {
-        const long long lo = (long long)atomicExch(acc64 + (int64_t)job * S + s, 0ull);
-        const long long hi = (long long)atomicExch(acc64 + ((int64_t)n_feat + job) * S + s, 0ull);
+        unsigned long long* __restrict__ plo = acc64 + (int64_t)job * S + s;
+        unsigned long long* __restrict__ phi = acc64 + ((int64_t)n_feat + job) * S + s;
+        const long long lo = (long long)*plo, hi = (long long)*phi;
+        *plo = 0ull;
+        *phi = 0ull;
         // sum = lo + 2^32 hi (an integer of up to ~95 bits) -> f64: the conversions and the FMA round at 2^-53 relative
         gb[(int64_t)dst_row[job] * S + s] = fma((double)hi, 0x1p32, (double)lo) * 0x1p-52;
     } else {
         const int j = job - n_feat;
         double acc = 0.0;
-        for (int c = 0; c < kRedChunks; ++c)  // chunk order: reproducible
-            acc += __longlong_as_double((long long)atomicExch(
-                reinterpret_cast<unsigned long long*>(bu_part) + ((int64_t)c * n_u + j) * S + s, 0ull));
+        for (int c = 0; c < kRedChunks; ++c) acc += bu_part[((int64_t)c * n_u + j) * S + s];  // chunk order: reproducible
         gb[(int64_t)dst_row[job] * S + s] = acc;
     }
 }
@@ -796,8 +781,7 @@ int64_t gram_i8_slab_words(int64_t N, int SD, int n_c, int n_u) {
 }
 int64_t gram_i8_acc_words(int S, int n_c, int n_u) {
     const int nf = n_c * n_u + n_u * (n_u + 1) / 2;
-    // + one arrival counter (int) per (job, sample block) of k_gram_v2_reduce's grid
-    return (int64_t)2 * nf * S + (int64_t)kRedChunks * n_u * S + ((int64_t)(nf + n_u) * ((S + 63) / 64) + 1) / 2;
+    return (int64_t)2 * nf * S + (int64_t)kRedChunks * n_u * S;
 }
 
 size_t gram_i8_w8_lds_bytes(int xl, int nd, int ring) { return (size_t)ring * (4096 * nd + xl * 4096) + (size_t)3 * 2 * (kNSL * 64) * 16; }
@@ -863,10 +847,10 @@ hipError_t launch_gram_v2_reduce(const long long* slab_i8, int ny, int NF, int S
     const int MF = (NF + 31) / 32 * 32;
     unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(acc_words);
     double* bu_part = reinterpret_cast<double*>(acc_words + (int64_t)2 * NF * S);
-    int* arrive = reinterpret_cast<int*>(acc_words + (int64_t)2 * NF * S + (int64_t)kRedChunks * n_u * S);  // zero at rest
     hipLaunchKernelGGL(k_gram_v2_reduce, dim3((S + 63) / 64, NF + n_u, kRedChunks), dim3(256), 0, st, slab_i8, ny, MF, SD,
-                       slab_bu, n_bu_slabs, n_u, NF, S, acc64, bu_part, arrive, dst_row, gb, done_flag, u2_partials, n_u2,
-                       state);
+                       slab_bu, n_bu_slabs, n_u, NF, S, acc64, bu_part, done_flag, u2_partials, n_u2, state);
+    hipLaunchKernelGGL(k_gram_v2_finish, dim3((S + 63) / 64, NF + n_u), dim3(64), 0, st, n_u, NF, S, acc64, bu_part, dst_row,
+                       gb, done_flag);
     return hipGetLastError();
 }
 
