@@ -297,18 +297,31 @@ def main():
             dom_kernel = "k_gram_reduce"
         dom_ms = fam_ms[dom][0]
         achieved = per_launch_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic, traffic_source = None, None
-        tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
+        # Counter figures of the dominant kernel: NOT measured in this run (counters need rocprofv3 passes of their own,
+        # one group per pass) but taken from profiles/counters.json, which tools/collect_counters.py writes from such
+        # passes and stamps with the commit they were taken at (profiles/README.md).
+        traffic, traffic_source, pmc = None, None, {}
+        for name in ("counters.json", "traffic.json"):
+            tfile = ROOT / "profiles" / name
+            if traffic is not None or not tfile.exists():
+                continue
             try:
                 tj = json.loads(tfile.read_text())
                 entry = tj.get(args.workload, {}).get(dom_kernel.split("<")[0], {})
                 traffic = entry.get("hbm_bytes_per_launch")
                 if traffic is not None:
-                    # NOT measured in this run: a rocprofv3 PMC capture (profiles/README.md) of the commit named here
-                    traffic_source = f"profiles/traffic.json@{tj.get('_commit', 'unknown')} (rocprofv3 --pmc, separate run)"
+                    traffic_source = f"profiles/{name}@{tj.get('_commit', 'unknown')} (rocprofv3 --pmc, separate run)"
+                    pmc = {k: entry.get(k) for k in ("issue_frac", "wait_frac", "mfma_busy_frac") if entry.get(k) is not None}
             except Exception:
                 traffic = None
+        # What bounds the dominant kernel, from the data: the roof it sits closest to if it reaches 0.7 of it -- HBM bytes,
+        # FP64 rate (this run), issue slots or matrix-pipe time (counters) -- otherwise none of them does: "latency"
+        # (dependency and memory stalls that the resident waves do not cover; see wait_frac).
+        hbm_frac = achieved / HBM_PEAK_GBS
+        fp64_frac = row_flop / (fam_ms["rowpass"][0] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if fam_ms["rowpass"][0] > 0 and dom == "rowpass" else 0.0
+        shares = {"hbm": hbm_frac, "fp64": fp64_frac, "issue": pmc.get("issue_frac", 0.0), "mfma": pmc.get("mfma_busy_frac", 0.0)}
+        top = max(shares, key=shares.get)
+        bound = top if shares[top] >= 0.7 else "latency"
         ms_per_step = elapsed / args.steps * 1e3
         loop_rate = iters_total / loop_s if loop_s > 0 else 0.0
         iter_bytes = row_bytes + gram_bytes
@@ -338,8 +351,11 @@ def main():
             "loop_only": {"value": loop_rate, "unit": "outer iters/s per GPU", "ms_per_outer_iteration": 1e3 / loop_rate if loop_rate else None,
                           "restarts_on_rank0": len(mine), "job_seconds": elapsed, "loop_seconds_rank0": loop_s},
             "roofline": {
-                "bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # achieved / peak / frac: against the HBM roof (the bytes the kernel must move), whatever `bound` says
+                "bound": bound, "bound_shares": {k: round(v, 4) for k, v in shares.items()},
+                "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "issue_frac": pmc.get("issue_frac"), "wait_frac": pmc.get("wait_frac"), "mfma_busy_frac": pmc.get("mfma_busy_frac"),
                 "algorithmic_bytes_per_launch": per_launch_bytes[dom],
                 "avg_launch_ms": dom_ms,
                 # the same launch against the FP64 roof: flops the row pass executes in this formulation (FP64 MFMA and
