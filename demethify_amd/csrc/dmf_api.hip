@@ -63,6 +63,7 @@ struct dmf_context {
     std::unordered_map<void*, size_t> live;                // large blocks handed out by pool_alloc (size by address)
     std::unordered_map<size_t, std::vector<void*>> kept;    // freed large blocks kept for the next allocation of that size
     size_t kept_bytes = 0;
+    std::vector<double*> pinned_moms;    // ... and of their momentum-row staging buffers
     std::vector<void*> pinned_states;   // page-locked SolverState mirrors of destroyed solvers, reused by the next ones
                                         // (hipHostMalloc / hipHostFree cost ~0.1 ms each: a restart loop makes one per restart)
     hipStream_t copy_stream = nullptr;  // dmf_stage_upload: uploads beside the kernels of `stream` (created on first use)
@@ -126,6 +127,9 @@ struct dmf_solver {
     // (confirm_stops), an iteration whose Gram-form |cf - cf_0| falls below kConfirmBand x tol pauses the device
     // (state->done = 2), and the host decides on the streaming cost of deconvolution.py:15-17 for this and the previous
     // iterate (cf_stream, cf_stream_iter), exactly the reference's formula.
+    // momentum rows (SolverState::mom): a page-locked staging buffer and its device copy, kMomRows rows of 2 + 2 kMomSteps
+    double* mom_host = nullptr;
+    double* mom_dev = nullptr;
     bool confirm_stops = false;
     double cf_stream = 0.0;
     long long cf_stream_iter = -1;
@@ -740,6 +744,7 @@ int dmf_context_destroy(dmf_context* ctx) {
     ctx->kept.clear();
     (void)hipStreamSynchronize(ctx->stream);
     for (void* h : ctx->pinned_states) (void)hipHostFree(h);
+    for (double* h : ctx->pinned_moms) (void)hipHostFree(h);
     if (ctx->copy_stream != nullptr) {
         hipStreamSynchronize(ctx->copy_stream);
         hipStreamDestroy(ctx->copy_stream);
@@ -1121,6 +1126,56 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     return DMF_OK;
 }
 
+constexpr int kMomRows = 64, kMomSteps = 64;  // momentum rows per upload (= the largest batch), inner steps a row can hold
+
+__global__ void k_set_momentum(SolverState* state, const double* mom, int stride, int rows, int n) {
+    state->mom = mom;
+    state->mom_stride = stride;
+    state->mom_rows = rows;
+    state->mom_i = 0;
+    state->mom_n = n;
+}
+
+// Runs the momentum recurrence (deconvolution.py:83-84 / :95-96: a <- (1 + sqrt(1 + 4 a^2)) / 2, and the ratio
+// (a_old - 1) / a that beta is the minimum of) ahead for `rows` outer iterations of n inner steps each, from the
+// solver's current (a1, a2), and uploads the rows; the kernels of those iterations read them instead of running the
+// recurrence themselves.  Plain IEEE double arithmetic, as numpy's in the reference (no contraction on the host).
+static double momentum_advance(double& a) {  // a <- next a; returns (a_old - 1) / a_new
+#pragma clang fp contract(off)
+    const double a0 = a;
+    const double sq = 4.0 * a0 * a0;
+    a = (1.0 + std::sqrt(1.0 + sq)) / 2.0;
+    return (a0 - 1.0) / a;
+}
+
+static int upload_momentum_rows(dmf_solver* s, int rows, int n) {
+    dmf_context* ctx = s->ctx;
+    const int stride = 2 + 2 * n;
+    if (s->mom_host == nullptr) {
+        if (!ctx->pinned_moms.empty()) {
+            s->mom_host = ctx->pinned_moms.back();
+            ctx->pinned_moms.pop_back();
+        } else {
+            HIP_TRY(hipHostMalloc((void**)&s->mom_host, (size_t)kMomRows * (2 + 2 * kMomSteps) * sizeof(double)));
+        }
+        HIP_TRY(pool_alloc(ctx, (void**)&s->mom_dev, (size_t)kMomRows * (2 + 2 * kMomSteps) * sizeof(double)));
+    }
+    double a1 = s->h_state->a1, a2 = s->h_state->a2;
+    for (int r = 0; r < rows; ++r) {
+        double* row = s->mom_host + (size_t)r * stride;
+        for (int t = 0; t < n; ++t) {
+            row[2 + t] = momentum_advance(a1);
+            row[2 + n + t] = momentum_advance(a2);
+        }
+        row[0] = a1;
+        row[1] = a2;
+    }
+    HIP_TRY(hipMemcpyAsync(s->mom_dev, s->mom_host, (size_t)rows * stride * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_set_momentum, dim3(1), dim3(1), 0, ctx->stream, s->state, (const double*)s->mom_dev, stride, rows, n);
+    HIP_TRY(hipGetLastError());
+    return DMF_OK;
+}
+
 // tol and the band factor of this step() call: the closing kernel pauses (done = 2) when |cf - cf_0| < band x tol
 // with band > 1, and stops (done = 1) when band == 1
 __global__ void k_set_tol(SolverState* state, double tol, double band) {
@@ -1175,9 +1230,18 @@ int dmf_solver_step(dmf_solver* s, int64_t n_outer, int64_t n_iter2, double tol,
     // times, and what a late stop costs is a few dozen no-op launches.
     int64_t check_every = s->spec.u_path != 2 ? 8 : 1;
     const long long iters0 = s->h_state->iters;
+    // momentum rows for the kernels that read them (the one-launch row pass and the DPP alpha kernel)
+    const dmf::IterationPlan plan = dmf::plan_iteration(s->key, s->spec, (int)n_iter2, s->purity != nullptr);
+    const bool use_mom = n_iter2 >= 1 && n_iter2 <= kMomSteps && plan.row == dmf::RowKind::RowpassV2 &&
+                         plan.alpha == dmf::AlphaKind::PhaseRow16;
+    if (!use_mom && s->h_state->mom_n >= 0) {  // (rows of an earlier call with another n_iter2 / another path: off)
+        hipLaunchKernelGGL(k_set_momentum, dim3(1), dim3(1), 0, ctx->stream, s->state, (const double*)nullptr, 0, 0, -1);
+        HIP_TRY(hipGetLastError());
+    }
     while (s->h_state->iters - iters0 < n_outer && s->h_state->done != 1) {
         const int64_t left = n_outer - (s->h_state->iters - iters0);
         const int64_t batch = left < check_every ? left : check_every;
+        if (use_mom) DMF_TRY(upload_momentum_rows(s, (int)batch, (int)n_iter2));  // (from h_state's a1 / a2: just fetched)
         for (int64_t b = 0; b < batch; ++b) DMF_TRY(enqueue_outer_iteration(s, (int)n_iter2));
         DMF_TRY(fetch_state(s));
         if (s->h_state->iters > iters0) s->cf_pending = false;  // (state->cf is the loop's cost from now on)
@@ -1276,6 +1340,8 @@ int dmf_solver_destroy(dmf_solver* s) {
     pool_free(ctx, s->u2_partials);
     pool_free(ctx, s->purity);
     pool_free(ctx, s->state);
+    pool_free(ctx, s->mom_dev);
+    if (s->mom_host) ctx->pinned_moms.push_back(s->mom_host);
     if (s->h_state) ctx->pinned_states.push_back(s->h_state);
     pool_free(ctx, s->job_k);
     pool_free(ctx, s->job_l);

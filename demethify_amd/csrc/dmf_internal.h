@@ -25,7 +25,22 @@ struct SolverState {
     double band;       // 1: |cf - cf_0| < tol stops; > 1: |cf - cf_0| < band x tol pauses for the host's confirmation
     int done;          // 1 once |cf - cf_0| < tol was met, 2 while paused: later launches are no-ops
     int arrive;        // workgroups of the alpha kernel that have finished this outer iteration (the last one closes it)
+    // Momentum rows (dmf_solver_step).  The sequence a_t of deconvolution.py:83-84 / :95-96 does not depend on the data, so
+    // the host runs it ahead for the iterations it enqueues and uploads one row per outer iteration:
+    //   { a1 after the iteration, a2 after it, (a_{t-1} - 1) / a_t for the u phase [mom_n], the same for the alpha phase }
+    // -- no kernel then spends its first microseconds on a chain of n_iter2 square roots and divisions (the row pass's
+    // thread 0, every wave of the alpha kernel and the closing step each did).  Row mom_i is the current iteration's
+    // (the closing step moves on); valid for launches with n_iter2 == mom_n only.
+    const double* mom;
+    int mom_stride, mom_rows, mom_i, mom_n;
 };
+
+// the row of momentum ratios of the current outer iteration, or nullptr (the kernel then runs the recurrence itself)
+__device__ __forceinline__ const double* momentum_row(const SolverState* __restrict__ state, int n_iter2) {
+    return (state->mom != nullptr && state->mom_n == n_iter2 && state->mom_i < state->mom_rows)
+               ? state->mom + (int64_t)state->mom_i * state->mom_stride
+               : nullptr;
+}
 
 // Packed upper triangle, column-major over (k <= l): independent of the matrix size.
 __host__ __device__ inline int tri(int k, int l) { return l * (l + 1) / 2 + k; }

@@ -262,9 +262,15 @@ __device__ __forceinline__ void finish_iteration_body(const double* __restrict__
     n2 = wave_sum(n2);
     if (threadIdx.x == 0) {
         double a1 = state->a1, a2 = state->a2;
-        for (int t = 0; t < n_iter2; ++t) {
-            a1 = (1.0 + sqrt(1.0 + 4.0 * a1 * a1)) / 2.0;
-            a2 = (1.0 + sqrt(1.0 + 4.0 * a2 * a2)) / 2.0;
+        if (const double* __restrict__ row = momentum_row(state, n_iter2)) {  // (run ahead by the host: SolverState)
+            a1 = row[0];
+            a2 = row[1];
+            state->mom_i += 1;
+        } else {
+            for (int t = 0; t < n_iter2; ++t) {
+                a1 = (1.0 + sqrt(1.0 + 4.0 * a1 * a1)) / 2.0;
+                a2 = (1.0 + sqrt(1.0 + 4.0 * a2 * a2)) / 2.0;
+            }
         }
         state->a1 = a1;
         state->a2 = a2;
@@ -495,9 +501,21 @@ __global__ __launch_bounds__(64) void k_alpha_phase_row16(const double* __restri
     double a2 = state->a2, lh_prev = state->l_h_prev;
     const double lh = state->l_h;
     const double rank1 = (double)(k + 1);
+    // momentum coefficients: from the host's row when there is one (lane t holds beta_t, read with v_readlane), else the
+    // recurrence itself, in every wave
+    const double* __restrict__ mrow = n_iter2 <= 64 ? momentum_row(state, n_iter2) : nullptr;
+    int b_lo = 0, b_hi = 0;
+    if (mrow != nullptr) {
+        const int tl = lane < n_iter2 ? lane : n_iter2 - 1;
+        const double cap = lane == 0 ? 0.9999 * sqrt(lh_prev / lh) : 0.9999;  // l_h_ = l_h behind the first step (:101)
+        const double bv = fmin(mrow[2 + n_iter2 + tl], cap);
+        b_lo = __double2loint(bv);
+        b_hi = __double2hiint(bv);
+    }
     for (int t = 0; t < n_iter2; ++t) {
         double beta;
-        momentum_step(a2, lh_prev, lh, beta);
+        if (mrow != nullptr) beta = __hiloint2double(__builtin_amdgcn_readlane(b_hi, t), __builtin_amdgcn_readlane(b_lo, t));
+        else momentum_step(a2, lh_prev, lh, beta);
         const double at = a + beta * (a - ap);
         ap = a;
         double g0 = bk, g1 = 0.0, g2 = 0.0, g3 = 0.0;  // b - G at
@@ -850,6 +868,8 @@ __global__ __launch_bounds__(256) void k_init_state(SolverState* __restrict__ st
         state->cf_prev = state->cf;
         state->tol = 0.0;
         state->band = 1.0;
+        state->mom = nullptr;
+        state->mom_n = -1;
         state->iters = 0;
         state->done = 0;
         state->arrive = 0;

@@ -163,10 +163,16 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
     float* __restrict__ tileD = reinterpret_cast<float*>(tile + kTileVBytes2);
     char* __restrict__ tileB = tile + kTileVBytes2 + kTileDBytes2;  // [2 digit planes][16][kRowB]: counts as balanced bytes
 
-    if (threadIdx.x == 0) {
+    // momentum coefficients of the inner steps (deconvolution.py:83-85): from the host's row of ratios when there is one
+    // (SolverState), else the recurrence itself by one thread -- n_iter2 square roots and divisions in a row, ~5 us
+    if (const double* __restrict__ mrow = momentum_row(state, n_iter2)) {
+        const double lw_prev = state->l_w_prev, lw = state->l_w;
+        for (int t2 = threadIdx.x; t2 < n_iter2; t2 += blockDim.x)
+            beta_tab[t2] = fmin(mrow[2 + t2], t2 == 0 ? 0.9999 * sqrt(lw_prev / lw) : 0.9999);  // l_w_ = l_w behind step 0 (:89)
+    } else if (threadIdx.x == 0) {
         double a1 = state->a1, lw_prev = state->l_w_prev;
         const double lw = state->l_w;
-        for (int t2 = 0; t2 < n_iter2; ++t2) {  // deconvolution.py:83-85
+        for (int t2 = 0; t2 < n_iter2; ++t2) {
             double beta;
             momentum_step(a1, lw_prev, lw, beta);
             beta_tab[t2] = beta;
