@@ -1229,6 +1229,8 @@ int dmf_solver_step(dmf_solver* s, int64_t n_outer, int64_t n_iter2, double tol,
     // The batches double (8, 16, 32, 64): a solve that runs for hundreds of iterations reads the state back a handful of
     // times, and what a late stop costs is a few dozen no-op launches.
     int64_t check_every = s->spec.u_path != 2 ? 8 : 1;
+    // (a threshold of zero never fires -- |cf - cf_0| < 0 -- so a fixed-work run needs no look at the state in between)
+    if (tol == 0.0 && s->spec.u_path != 2) check_every = kMomRows;
     const long long iters0 = s->h_state->iters;
     // momentum rows for the kernels that read them (the one-launch row pass and the DPP alpha kernel)
     const dmf::IterationPlan plan = dmf::plan_iteration(s->key, s->spec, (int)n_iter2, s->purity != nullptr);

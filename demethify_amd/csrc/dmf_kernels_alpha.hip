@@ -458,12 +458,16 @@ __device__ __forceinline__ double row_xor(double x, int k) {
     }
 }
 
-// acc += x[lane L of the row] * m   (the s_nop covers the VALU-write -> DPP-read hazard inside the asm)
-template <int L>
+// acc += x[lane L of the row] * m   (the s_nop covers the VALU-write -> DPP-read hazard inside the asm: FIRST = the first
+// read of a freshly written x; the reads behind it need none)
+template <int L, bool FIRST = true>
 __device__ __forceinline__ void fmac_rowbcast(double& acc, double x, double m) {
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                 : "+v"(acc)
-                 : "v"(x), "v"(m), "n"(L));
+    if constexpr (FIRST)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc)
+                     : "v"(x), "v"(m), "n"(L));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(L));
 }
 
 template <int J>
@@ -518,48 +522,80 @@ __global__ __launch_bounds__(64) void k_alpha_phase_row16(const double* __restri
         else momentum_step(a2, lh_prev, lh, beta);
         const double at = a + beta * (a - ap);
         ap = a;
-        double g0 = bk, g1 = 0.0, g2 = 0.0, g3 = 0.0;  // b - G at
-        fmac_rowbcast<0>(g0, at, Gneg[0]);   fmac_rowbcast<1>(g1, at, Gneg[1]);
-        fmac_rowbcast<2>(g2, at, Gneg[2]);   fmac_rowbcast<3>(g3, at, Gneg[3]);
-        fmac_rowbcast<4>(g0, at, Gneg[4]);   fmac_rowbcast<5>(g1, at, Gneg[5]);
-        fmac_rowbcast<6>(g2, at, Gneg[6]);   fmac_rowbcast<7>(g3, at, Gneg[7]);
-        fmac_rowbcast<8>(g0, at, Gneg[8]);   fmac_rowbcast<9>(g1, at, Gneg[9]);
-        fmac_rowbcast<10>(g2, at, Gneg[10]); fmac_rowbcast<11>(g3, at, Gneg[11]);
-        fmac_rowbcast<12>(g0, at, Gneg[12]); fmac_rowbcast<13>(g1, at, Gneg[13]);
-        fmac_rowbcast<14>(g2, at, Gneg[14]); fmac_rowbcast<15>(g3, at, Gneg[15]);
+        // b - G at, four interleaved chains; the columns beyond K are zero and skipped in fours (K is wave-uniform)
+        double g0 = bk, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+        fmac_rowbcast<0>(g0, at, Gneg[0]);          fmac_rowbcast<1, false>(g1, at, Gneg[1]);
+        fmac_rowbcast<2, false>(g2, at, Gneg[2]);   fmac_rowbcast<3, false>(g3, at, Gneg[3]);
+        if (K > 4) {
+            fmac_rowbcast<4, false>(g0, at, Gneg[4]);   fmac_rowbcast<5, false>(g1, at, Gneg[5]);
+            fmac_rowbcast<6, false>(g2, at, Gneg[6]);   fmac_rowbcast<7, false>(g3, at, Gneg[7]);
+        }
+        if (K > 8) {
+            fmac_rowbcast<8, false>(g0, at, Gneg[8]);   fmac_rowbcast<9, false>(g1, at, Gneg[9]);
+            fmac_rowbcast<10, false>(g2, at, Gneg[10]); fmac_rowbcast<11, false>(g3, at, Gneg[11]);
+        }
+        if (K > 12) {
+            fmac_rowbcast<12, false>(g0, at, Gneg[12]); fmac_rowbcast<13, false>(g1, at, Gneg[13]);
+            fmac_rowbcast<14, false>(g2, at, Gneg[14]); fmac_rowbcast<15, false>(g3, at, Gneg[15]);
+        }
         const double g = (g0 + g1) + (g2 + g3);
         const double x = at + g / lh;  // deconvolution.py:100: alpha_temp + (...) / l_h
-        // ---- projection onto the simplex (deconvolution.py:25-35): bitonic sort of the row, descending
+        // ---- projection onto the simplex (deconvolution.py:25-35): bitonic sort of the row, descending.  The lanes
+        // beyond K hold -inf: with K <= 8 (4, 2) only the first 8 (4, 2) lanes need sorting -- the last stage then runs
+        // "whole row descending" (k2 = 16) on the shorter network.
         double srt = row_ok ? x : -INFINITY;
-        bitonic_step<1>(srt, k, 2);
-        bitonic_step<2>(srt, k, 4);  bitonic_step<1>(srt, k, 4);
-        bitonic_step<4>(srt, k, 8);  bitonic_step<2>(srt, k, 8);  bitonic_step<1>(srt, k, 8);
-        bitonic_step<8>(srt, k, 16); bitonic_step<4>(srt, k, 16); bitonic_step<2>(srt, k, 16);
-        bitonic_step<1>(srt, k, 16);
+        if (K > 8) {
+            bitonic_step<1>(srt, k, 2);
+            bitonic_step<2>(srt, k, 4);  bitonic_step<1>(srt, k, 4);
+            bitonic_step<4>(srt, k, 8);  bitonic_step<2>(srt, k, 8);  bitonic_step<1>(srt, k, 8);
+            bitonic_step<8>(srt, k, 16); bitonic_step<4>(srt, k, 16); bitonic_step<2>(srt, k, 16);
+            bitonic_step<1>(srt, k, 16);
+        } else if (K > 4) {
+            bitonic_step<1>(srt, k, 2);
+            bitonic_step<2>(srt, k, 4);  bitonic_step<1>(srt, k, 4);
+            bitonic_step<4>(srt, k, 16); bitonic_step<2>(srt, k, 16); bitonic_step<1>(srt, k, 16);
+        } else if (K > 2) {
+            bitonic_step<1>(srt, k, 2);
+            bitonic_step<2>(srt, k, 16); bitonic_step<1>(srt, k, 16);
+        } else {
+            bitonic_step<1>(srt, k, 16);
+        }
         double cum = row_ok ? srt : 0.0;  // padded lanes sort to the end (-inf) and add nothing
         cum += dpp16<0x111, true>(cum);   // row_shr:1 .. 8, lanes without a source read 0: inclusive scan
         cum += dpp16<0x112, true>(cum);
-        cum += dpp16<0x114, true>(cum);
-        cum += dpp16<0x118, true>(cum);
-        const double shifted = cum - 1.0;
-        const bool cond = row_ok && fma(srt, rank1, -shifted) > 0.0;
-        const unsigned long long ball = __ballot(cond);
-        const unsigned int mine = (unsigned int)((ball >> base) & 0xFFFFull);
-        // rho = last lane of the row whose condition holds (lane 0 always does for finite input)
-        const int rho = mine ? 31 - __clz((int)mine) : -1;
-        const double num = __shfl(shifted, base + (rho >= 0 ? rho : K - 1), 64);
-        const double theta = rho >= 0 ? num / (double)(rho + 1) : num / 0.0;
-        a = row_ok ? fmax(x - theta, 0.0) : 0.0;
+        if (K > 4) cum += dpp16<0x114, true>(cum);
+        if (K > 8) cum += dpp16<0x118, true>(cum);
+        // theta = (cumsum_rho - 1) / (rho + 1) with rho the LAST position where u_rho - (cumsum_rho - 1) / (rho + 1) > 0
+        // (:28-33).  t_j = (cumsum_j - 1) / (j + 1) grows exactly while that condition holds -- t_(j+1) - t_j =
+        // (u_(j+1) - t_j) / (j + 2), and u_(j+1) > t_(j+1) <=> u_(j+1) > t_j -- and never again behind rho (u keeps falling,
+        // t_j >= u_j from there on), so theta is the row's MAXIMUM of t_j: every lane divides once (one instruction
+        // sequence for the wave, as the one division at rho was) and four DPP steps take the maximum, instead of a
+        // ballot, a count of leading zeros and an LDS round trip (ds_bpermute) to fetch cumsum_rho on the critical chain.
+        // Same value as the reference's up to the rounding of a near-tie between t_rho and t_(rho+1).
+        double tj = row_ok ? (cum - 1.0) / rank1 : -INFINITY;
+        tj = fmax(tj, row_xor<1>(tj, k));
+        tj = fmax(tj, row_xor<2>(tj, k));
+        if (K > 4) tj = fmax(tj, row_xor<4>(tj, k));
+        if (K > 8) tj = fmax(tj, row_xor<8>(tj, k));
+        a = row_ok ? fmax(x - tj, 0.0) : 0.0;
         lh_prev = lh;
     }
     if (col_ok && row_ok) {
         alpha[(int64_t)k * S + s] = a;
         alpha_prev[(int64_t)k * S + s] = ap;
     }
-    // cost_s = vDv - 2 a.b + a^T G a ; ||alpha_unknown||^2
-    double ga = 0.0;
-#pragma unroll
-    for (int l = 0; l < 16; ++l) ga = fma(-Gneg[l], __shfl(a, base + l, 64), ga);
+    // cost_s = vDv - 2 a.b + a^T G a ; ||alpha_unknown||^2.  (G a as one chain of DPP row broadcasts in column order: the
+    // same sum, term by term, as sixteen ds_bpermute round trips gave -- fma(-x, y, -z) = -fma(x, y, z).)
+    double nga = 0.0;
+    fmac_rowbcast<0>(nga, a, Gneg[0]);          fmac_rowbcast<1, false>(nga, a, Gneg[1]);
+    fmac_rowbcast<2, false>(nga, a, Gneg[2]);   fmac_rowbcast<3, false>(nga, a, Gneg[3]);
+    fmac_rowbcast<4, false>(nga, a, Gneg[4]);   fmac_rowbcast<5, false>(nga, a, Gneg[5]);
+    fmac_rowbcast<6, false>(nga, a, Gneg[6]);   fmac_rowbcast<7, false>(nga, a, Gneg[7]);
+    fmac_rowbcast<8, false>(nga, a, Gneg[8]);   fmac_rowbcast<9, false>(nga, a, Gneg[9]);
+    fmac_rowbcast<10, false>(nga, a, Gneg[10]); fmac_rowbcast<11, false>(nga, a, Gneg[11]);
+    fmac_rowbcast<12, false>(nga, a, Gneg[12]); fmac_rowbcast<13, false>(nga, a, Gneg[13]);
+    fmac_rowbcast<14, false>(nga, a, Gneg[14]); fmac_rowbcast<15, false>(nga, a, Gneg[15]);
+    const double ga = -nga;
     double part = col_ok ? fma(a, ga, -2.0 * a * bk) : 0.0;
     if (col_ok && k == 0) part += gb[(int64_t)tri(K, K) * S + sc];
     double n2 = (col_ok && row_ok && k >= K - n_u) ? a * a : 0.0;
