@@ -22,7 +22,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").split("::")[-1]
+    return name.split("(")[0].replace("void ", "").split("::")[-1].split("<")[0]  # (instantiations of one kernel together)
 
 
 def counters(root, sub):
