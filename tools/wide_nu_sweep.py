@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: ms per outer iteration for wide row groups (n_u 5..16) at 5e5 x 128 and 2.5e5 x 256.
-   python tools/wide_nu_sweep.py            (set DMF_CM_I8_MIN_NU=99 to see the kernels that ran before k_cm_i8)"""
+   python tools/wide_nu_sweep.py            (DMF_CM_I8_MIN_NU=99 shows the kernels that ran before k_cm_i8 -- in an experiment
+   build only: DMF_EXPERIMENT=1 python -m demethify_amd._build --force; the product build has no environment knobs)"""
 import sys, time
 from pathlib import Path
 import numpy as np
