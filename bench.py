@@ -225,20 +225,33 @@ def main():
     # ------------------------------------------------------------------ timed region: the restart job
     feeder = staging.Prefetcher(mine, lambda k: restart_init_on_device(k, (N, S, n_c, n_u), ctx), depth=2, workers=2)
     best, local_costs, loop_s, iters_total = None, {}, 0.0, 0
-    for k, (u0, a0) in feeder:
-        s = Solver(problem, u0, a0, L.DMF_MODE_PARTIAL)
-        tl = time.perf_counter()
-        it, _ = s.step(args.steps, T2, 0.0)  # returns after the last iteration's state has been read back
-        loop_s += time.perf_counter() - tl
-        iters_total += it
-        cost = s.direct_cost()               # cost_f_w per restart, demethify.py:199
+
+    def settle(k, s):
+        """cost_f_w of restart k (demethify.py:199) has been on its way since the restart's loop ended: take it, keep the
+        solver if it is the new minimum (strict '<': the first minimum wins, demethify.py:200)."""
+        nonlocal best
+        cost = s.cost_end()
         local_costs[k] = cost
-        if best is None or cost < best[0]:   # strict '<': the first minimum wins (demethify.py:200)
+        if best is None or cost < best[0]:
             if best is not None:
                 best[2].close()
             best = (cost, k, s)
         else:
             s.close()
+
+    waiting = None
+    for k, (u0, a0) in feeder:
+        s = Solver(problem, u0, a0, L.DMF_MODE_PARTIAL)  # (set up while the GPU takes the previous restart's cost)
+        if waiting is not None:
+            settle(*waiting)
+        tl = time.perf_counter()
+        it, _ = s.step(args.steps, T2, 0.0)  # returns after the last iteration's state has been read back
+        loop_s += time.perf_counter() - tl
+        iters_total += it
+        s.cost_begin()
+        waiting = (k, s)
+    if waiting is not None:
+        settle(*waiting)
     costs = shard.allreduce_min_vector(local_costs, R)  # ONE all-reduce(min), 8 R bytes
     best_k = shard.argmin_first(costs)
     owner = best_k % world

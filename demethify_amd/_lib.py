@@ -52,6 +52,8 @@ SIGNATURES = {
     "dmf_solver_step": (C.c_int, [_p, _i64, _i64, C.c_double, C.POINTER(_i64), C.POINTER(C.c_int)]),
     "dmf_solver_get": (C.c_int, [_p, C.c_int, _p, _p, _dbl_p, C.POINTER(_i64)]),
     "dmf_solver_cost": (C.c_int, [_p, _dbl_p]),
+    "dmf_solver_cost_begin": (C.c_int, [_p]),
+    "dmf_solver_cost_end": (C.c_int, [_p, _dbl_p]),
     "dmf_solver_destroy": (C.c_int, [_p]),
     "dmf_solver_describe": (C.c_int, [_p, _i64, C.c_char_p, _i64]),
     "dmf_select_describe": (C.c_int, [_i64, _i64, _i64, _i64, C.c_int, C.c_int, _i64, C.c_int, C.c_char_p, _i64]),

@@ -63,6 +63,7 @@ struct dmf_context {
     std::unordered_map<void*, size_t> live;                // large blocks handed out by pool_alloc (size by address)
     std::unordered_map<size_t, std::vector<void*>> kept;    // freed large blocks kept for the next allocation of that size
     size_t kept_bytes = 0;
+    std::vector<hipEvent_t> events;       // ... and of their cost events
     std::vector<double*> pinned_moms;    // ... and of their momentum-row staging buffers
     std::vector<void*> pinned_states;   // page-locked SolverState mirrors of destroyed solvers, reused by the next ones
                                         // (hipHostMalloc / hipHostFree cost ~0.1 ms each: a restart loop makes one per restart)
@@ -90,6 +91,9 @@ struct dmf_problem {
     bool d_f32_exact = false;    // every count survives a round trip through f32 (the fused tile stores D as f32)
     double* gb_known = nullptr;  // [(n_c+1)(n_c+2)/2][S]
 };
+
+// page-locked per-solver block: the SolverState mirror, then one double for dmf_solver_cost_begin's result
+constexpr size_t kPinnedStateBytes = (sizeof(SolverState) + 15) / 16 * 16 + 16;
 
 struct dmf_solver {
     dmf_context* ctx = nullptr;
@@ -130,6 +134,13 @@ struct dmf_solver {
     // momentum rows (SolverState::mom): a page-locked staging buffer and its device copy, kMomRows rows of 2 + 2 kMomSteps
     double* mom_host = nullptr;
     double* mom_dev = nullptr;
+    // dmf_solver_cost_begin / _end: the streaming cost taken WITHOUT waiting for it (the caller sets up its next solver
+    // meanwhile); the event marks the result's arrival in the page-locked slot behind h_state
+    hipEvent_t cost_event = nullptr;
+    bool cost_pending = false;
+    // Has anything been enqueued for this solver since the host last waited for the stream?  (dmf_solver_destroy then
+    // waits; otherwise it must not: another solver's work may be running on the context's stream.)
+    bool in_flight = true;
     bool confirm_stops = false;
     double cf_stream = 0.0;
     long long cf_stream_iter = -1;
@@ -551,6 +562,7 @@ int enqueue_alpha_phase(dmf_solver* s, int n_iter2) {
 
 int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
     dmf_context* ctx = s->ctx;
+    s->in_flight = true;
     const dmf_problem* p = s->p;
     // which kernels: dmf_select.hip (one table for create / enqueue / describe)
     const dmf::IterationPlan plan = dmf::plan_iteration(s->key, s->spec, n_iter2, s->purity != nullptr);
@@ -642,6 +654,7 @@ int enqueue_outer_iteration(dmf_solver* s, int n_iter2) {
 int fetch_state(dmf_solver* s) {
     HIP_TRY(hipMemcpyAsync(s->h_state, s->state, sizeof(SolverState), hipMemcpyDeviceToHost, s->ctx->stream));
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    s->in_flight = false;
     return DMF_OK;
 }
 
@@ -745,6 +758,7 @@ int dmf_context_destroy(dmf_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (void* h : ctx->pinned_states) (void)hipHostFree(h);
     for (double* h : ctx->pinned_moms) (void)hipHostFree(h);
+    for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     if (ctx->copy_stream != nullptr) {
         hipStreamSynchronize(ctx->copy_stream);
         hipStreamDestroy(ctx->copy_stream);
@@ -1097,7 +1111,7 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
             s->h_state = (SolverState*)ctx->pinned_states.back();
             ctx->pinned_states.pop_back();
         } else {
-            e = hipHostMalloc((void**)&s->h_state, sizeof(SolverState));
+            e = hipHostMalloc((void**)&s->h_state, kPinnedStateBytes);  // (state mirror + the cost slot of cost_begin / cost_end)
         }
     }
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&s->job_k, s->n_jobs * sizeof(short));
@@ -1322,11 +1336,47 @@ int dmf_solver_cost(dmf_solver* s, double* out_cost) {
     return DMF_OK;
 }
 
+int dmf_solver_cost_begin(dmf_solver* s) {
+    if (s == nullptr) return DMF_ERR_BAD_ARG;
+    dmf_context* ctx = s->ctx;
+    DMF_TRY(check_ctx(ctx));
+    if (s->cost_event == nullptr) {
+        if (!ctx->events.empty()) {
+            s->cost_event = ctx->events.back();
+            ctx->events.pop_back();
+        } else {
+            HIP_TRY(hipEventCreateWithFlags(&s->cost_event, hipEventDisableTiming));
+        }
+    }
+    double* slot = reinterpret_cast<double*>(reinterpret_cast<char*>(s->h_state) + kPinnedStateBytes - 16);
+    {
+        FamilyScope scope(ctx, DMF_KERNEL_COST);
+        HIP_TRY(enqueue_cost(ctx, s->p, s->u, s->alpha, (int)s->n_u, ctx->scratch + 1024, ctx->scratch + 3072));
+    }
+    HIP_TRY(hipMemcpyAsync(slot, ctx->scratch + 3072, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipEventRecord(s->cost_event, ctx->stream));
+    s->cost_pending = true;
+    return DMF_OK;
+}
+
+int dmf_solver_cost_end(dmf_solver* s, double* out_cost) {
+    if (s == nullptr || out_cost == nullptr || !s->cost_pending) return DMF_ERR_BAD_ARG;
+    DMF_TRY(check_ctx(s->ctx));
+    HIP_TRY(hipEventSynchronize(s->cost_event));
+    s->cost_pending = false;
+    *out_cost = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(s->h_state) + kPinnedStateBytes - 16);
+    return DMF_OK;
+}
+
 int dmf_solver_destroy(dmf_solver* s) {
     if (s == nullptr) return DMF_OK;
     dmf_context* ctx = s->ctx;
     hipSetDevice(s->ctx->device);
-    hipStreamSynchronize(s->ctx->stream);
+    // The solver's buffers go back to the context's pool / free lists, whose reuse is ordered on the context's stream, and
+    // its page-locked blocks to the next solver: what must not be in flight is a transfer INTO or OUT OF those blocks.
+    if (s->cost_pending) (void)hipEventSynchronize(s->cost_event);
+    if (s->in_flight) (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->cost_event) ctx->events.push_back(s->cost_event);
     pool_free(ctx, s->u);
     pool_free(ctx, s->u_prev);
     pool_free(ctx, s->u_next);

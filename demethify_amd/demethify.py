@@ -211,18 +211,27 @@ def main(argv=None):
             def solve_one(k, best_cost, prepared):
                 u0, a0 = prepared
                 mode = L.DMF_MODE_UNSUPERVISED if unsupervised else L.DMF_MODE_PARTIAL
-                with Solver(problem, u0, a0, mode) as s:
+                s = Solver(problem, u0, a0, mode)
+                try:
                     if purity is not None and not unsupervised:
                         s.set_purity(purity)
                     s.step(args.iterations[0], args.iterations[1], args.termination)
-                    cost = s.direct_cost()  # cost_f_w recomputed per restart, demethify.py:169,199
+                    s.cost_begin()  # cost_f_w recomputed per restart (demethify.py:169,199): taken while the next one is set up
+                except BaseException:
+                    s.close()
+                    raise
+                return s
+
+            def solve_end(s, best_cost):
+                with s:
+                    cost = s.cost_end()
                     if not cost < best_cost and args.restart > 1:
                         return None, None, cost  # cannot win (strict '<', demethify.py:170,200): stays on the device
                     u, alpha, _, _ = s.get()
                 return u, alpha, cost
 
             ref_estimate, proportions, _best, _costs = shard.sharded_restarts(
-                args.restart, solve_one, ((meth_f.shape[0], n_u), (K, meth_f.shape[1])), prepare=prepare)
+                args.restart, solve_one, ((meth_f.shape[0], n_u), (K, meth_f.shape[1])), prepare=prepare, solve_end=solve_end)
         unknown_header = ["unknown_cell_" + str(i + 1) for i in range(n_u)]
         header = unknown_header if unsupervised else header + unknown_header
     elif n_u == 0 and meth_f.shape[1] >= 1:

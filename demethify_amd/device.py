@@ -334,6 +334,15 @@ class Solver:
         L.check(self._lib.dmf_solver_cost(self._h, C.byref(out)), "dmf_solver_cost")
         return out.value
 
+    def cost_begin(self):
+        """Enqueue direct_cost() without waiting for it (dmf_solver_cost_begin): set up the next solver, then cost_end()."""
+        L.check(self._lib.dmf_solver_cost_begin(self._h), "dmf_solver_cost_begin")
+
+    def cost_end(self) -> float:
+        out = C.c_double()
+        L.check(self._lib.dmf_solver_cost_end(self._h, C.byref(out)), "dmf_solver_cost_end")
+        return out.value
+
     def describe(self, n_iter2: int = 20) -> str:
         """Which kernels a step with n_iter2 inner iterations launches (dmf_solver_describe)."""
         buf = C.create_string_buffer(512)

@@ -205,8 +205,12 @@ def restart_seed(seed, k):
     return seed + k
 
 
-def sharded_restarts(n_restarts, solve_one, shapes, prepare=None):
+def sharded_restarts(n_restarts, solve_one, shapes, prepare=None, solve_end=None):
     """Run restarts k = 0..n_restarts-1 across the ranks and return the min-cost one everywhere.
+
+    With ``solve_end`` the restart is taken in two halves: solve_one(k, best_cost[, prepared]) returns a HANDLE (a solver
+    whose streaming cost is on its way: Solver.cost_begin) and solve_end(handle, best_cost) -> (u, alpha, cost) is called
+    once the NEXT restart has been set up and solved -- the GPU takes restart k's cost while the host prepares k + 1.
 
     solve_one(k, best_cost) -> (u, alpha, cost) runs restart k on this rank's GPU; it may return (None, None,
     cost) when cost >= best_cost (this rank's running minimum: the iterate of a restart that cannot win need not
@@ -224,14 +228,27 @@ def sharded_restarts(n_restarts, solve_one, shapes, prepare=None):
         source = iter(feed)
     else:
         feed, source = None, ((k, None) for k in mine)
+    def record(k, result):
+        nonlocal keep
+        u, alpha, cost = result
+        local_costs[k] = cost
+        # keep only the local best: strict '<' so that the lowest k wins ties locally as well
+        if not keep or cost < keep["cost"]:
+            keep = {"k": k, "u": u, "alpha": alpha, "cost": cost}
+
     try:
+        waiting = None
         for k, prepared in source:
             best_cost = keep["cost"] if keep else float("inf")
-            u, alpha, cost = solve_one(k, best_cost) if prepare is None else solve_one(k, best_cost, prepared)
-            local_costs[k] = cost
-            # keep only the local best: strict '<' so that the lowest k wins ties locally as well
-            if not keep or cost < keep["cost"]:
-                keep = {"k": k, "u": u, "alpha": alpha, "cost": cost}
+            out = solve_one(k, best_cost) if prepare is None else solve_one(k, best_cost, prepared)
+            if solve_end is None:
+                record(k, out)
+                continue
+            if waiting is not None:  # (restart k ran against the minimum BEFORE waiting's cost was known: solve_end decides)
+                record(waiting[0], solve_end(waiting[1], keep["cost"] if keep else float("inf")))
+            waiting = (k, out)
+        if waiting is not None:
+            record(waiting[0], solve_end(waiting[1], keep["cost"] if keep else float("inf")))
     finally:
         if feed is not None:
             feed.close()

@@ -165,6 +165,12 @@ int dmf_solver_get(dmf_solver* s, int flags, double* out_u, double* out_alpha,
  * (deconvolution.py:15-17), without moving u / alpha to the host: what the restart and model-selection loops
  * recompute after every solve (demethify.py:169,199; ic.py:206).  out_cost: host double. */
 int dmf_solver_cost(dmf_solver* s, double* out_cost);
+/* The same in two halves, for loops that run solve after solve (demethify.py:165-171,195-201; bootstrap.py:26; ic.py:192):
+ * _begin enqueues the cost of the current iterate and returns at once, _end waits for it -- in between the caller sets up
+ * (and may start stepping) its NEXT solver on the same context, so the GPU works on the cost while the host prepares.
+ * One cost in flight per solver; the iterate must not be stepped between the two calls. */
+int dmf_solver_cost_begin(dmf_solver* s);
+int dmf_solver_cost_end(dmf_solver* s, double* out_cost);
 int dmf_solver_destroy(dmf_solver* s);
 /* Which kernels a step with n_iter2 inner iterations would launch for this solver, as text, e.g.
  * "rowpass=k_rowpass_fused<3,4> nw=4 grid=256 tail=5 gram=fused alpha=k_alpha_phase_row16".  For tests (every

@@ -231,3 +231,33 @@ def test_staged_initialisation_is_the_same_solve(toy, ctx):
     assert c_host == c_dev
     np.testing.assert_array_equal(u_h, u_d)
     np.testing.assert_array_equal(a_h, a_d)
+
+
+def test_cost_in_two_halves_equals_direct_cost(ctx, toy):
+    """dmf_solver_cost_begin / _end (the restart loops take a restart's cost_f_w while they set up the next one): the same
+    bits as dmf_solver_cost, also with another solver created, stepped and destroyed in between, and a solver may be
+    destroyed with its cost still on its way."""
+    from demethify_amd import _lib as L
+    from demethify_amd.device import Problem, Solver
+
+    V, D, ref, _ = toy
+    u0, R, a0 = osol.init_partial("uniform_", V, D, ref, 2, seed=3)
+    with Problem(ctx, V, D, ref) as p:
+        with Solver(p, u0, a0, L.DMF_MODE_PARTIAL) as s:
+            s.step(3, 20, 0.0)
+            want = s.direct_cost()
+            s.cost_begin()
+            with Solver(p, u0, a0, L.DMF_MODE_PARTIAL) as other:
+                other.step(2, 20, 0.0)
+            assert s.cost_end() == want
+            with pytest.raises(L.DemethifyHipError):
+                s.cost_end()  # nothing on its way
+            s.cost_begin()
+            assert s.cost_end() == want
+        s2 = Solver(p, u0, a0, L.DMF_MODE_PARTIAL)
+        s2.step(1, 20, 0.0)
+        s2.cost_begin()
+        s2.close()
+        with Solver(p, u0, a0, L.DMF_MODE_PARTIAL) as s3:
+            s3.step(3, 20, 0.0)
+            assert s3.direct_cost() == want
