@@ -1132,6 +1132,9 @@ int dmf_solver_create(dmf_context* ctx, const dmf_problem* p, const double* u0, 
     // (the cost before the loop, deconvolution.py:204: when a stop test needs it -- dmf_solver_step)
     if (e == hipSuccess) e = dmf::launch_init_state(s->state, p->consts, s->alpha, (int)S, (int)n_c, (int)n_u, ctx->stream);
     s->confirm_stops = false;  // (set per step() call from tol: dmf_solver_step)
+    // Host arrays belong to the caller again when this returns: wait for the copies out of them.  (Device arrays -- the
+    // restart loops' staged uploads -- are read in stream order; their release is stream-ordered too: dmf_stage_free.)
+    if (e == hipSuccess && !(flags & DMF_PTR_DEVICE)) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         dmf_solver_destroy(s);
         return hip_fail(e, "solver set-up", __LINE__);
