@@ -403,7 +403,9 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
             if (XL == ND || wave < 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 5) * ND) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 5) * XL) : "memory");
             DMFG_STAMP(1)
+#ifndef DMF_GABL_BARRIER
             __builtin_amdgcn_s_barrier();
+#endif
             DMFG_STAMP(2)
             // Block b's seven MFMAs (operands in registers since the last iteration), one per piece of the conversion of
             // block b + 2 (rows in registers likewise), in this order and no other.  Each register is refilled from LDS
@@ -417,23 +419,33 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
             for (int t = 0; t < kNSL; ++t) {
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
+#ifndef DMF_GABL_MFMA
                     acc[t + d] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[t], bq[d], acc[t + d], 0, 0, 0);
+#endif
                     // (the conversion pieces sit behind the first MFMAs of the block: one per MFMA)
                     const int slot = t * ND + d;
+#ifndef DMF_GABL_CONV
                     if (slot < 4) convert_row(slot);
                     else if (slot == 4) transpose4(lo, tl);
                     else if (slot == 5) transpose4(hi, th);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
+#ifndef DMF_GABL_ROWS
                     if (slot < 4) {
                         xa[slot] = *reinterpret_cast<const double*>(rowA + slot * strideA + row_off);
                         xv[slot] = *reinterpret_cast<const double*>(rowB + slot * strideB + row_off);
                     }
+#endif
+#ifndef DMF_GABL_AOP
                     if (d == ND - 1) aop[t] = *reinterpret_cast<const v4i*>(at_next + ((t * MF) << 2));
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#ifndef DMF_GABL_BQ
 #pragma unroll
             for (int d = 0; d < ND; ++d) bq[d] = *reinterpret_cast<const v4i*>(bsrc + d * 1024 + op_off);
+#endif
             DMFG_STAMP(3)
             {   // DMA of block b + RING - 1 into the slot of block b - 1 (its count tile and rows went to registers long
                 // ago), here rather than at the head of the iteration: while this wave waits for the load path to take
@@ -445,11 +457,15 @@ __global__ __launch_bounds__(512) void k_gram_i8_w8(const signed char* __restric
                     if (x >= n_dma) break;
                     int64_t off = (int64_t)jc * gstep[x];
                     if (tail_clamp && jc == nb - 1) off = off < glim[x] ? off : glim[x];
+#ifndef DMF_GABL_DMA
                     __builtin_amdgcn_global_load_lds((gmem_void*)(gbase[x] + off), (lds_int*)(slot + lds_dst[x]), 16, 0, 0);
+#endif
                 }
             }
             DMFG_STAMP(5)
+#ifndef DMF_GABL_STORE
             store_digits(a_gen);
+#endif
             a_cur = a_next;
             DMFG_STAMP(4)
         }

@@ -7,6 +7,9 @@
 #include <cstdio>
 #include <random>
 #include <vector>
+#ifndef PROBE_RING
+#define PROBE_RING 8
+#endif
 using namespace dmf;
 int main() {
     const int64_t N = 1000000; const int S = 256, n_c = 12, n_u = 4, SD = 256, ND = 1;
@@ -27,12 +30,12 @@ int main() {
     int nsh, ny; int64_t rpw; gram_i8_geometry(N, SD, &nsh, &ny, &rpw);
     const int64_t words = gram_i8_slab_words(N, SD, n_c, n_u);
     hipMalloc(&slab, words * 8); hipMalloc(&stamps, (size_t)nsh * ny * 8 * 8 * 8); hipMemset(stamps, 0, (size_t)nsh * ny * 8 * 8 * 8);
-    const size_t lds = gram_i8_w8_lds_bytes(1, 1, 8);
-    hipFuncSetAttribute((const void*)k_gram_i8_w8<1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = gram_i8_w8_lds_bytes(1, 1, PROBE_RING);
+    hipFuncSetAttribute((const void*)k_gram_i8_w8<1, 1, PROBE_RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_gram_i8_w8<1, 1, 8>), dim3(nsh * ny), dim3(512), lds, 0, Dt8, plane, SD / 32, R, 12, u, N, n_c, n_u, dfa, dfb, NF, 0, 64, rpw, slab, SD, (const int*)nullptr
+        hipLaunchKernelGGL((k_gram_i8_w8<1, 1, PROBE_RING>), dim3(nsh * ny), dim3(512), lds, 0, Dt8, plane, SD / 32, R, 12, u, N, n_c, n_u, dfa, dfb, NF, 0, 64, rpw, slab, SD, (const int*)nullptr
 #ifdef DMF_STAMPS
                            , stamps
 #endif
