@@ -213,10 +213,11 @@ def test_config5_shape_properties(ctx):
 @pytest.mark.parametrize("N,S,n_c,n_u,depth", [(1500, 64, 16, 4, 2500), (4096, 256, 12, 4, 60), (20000, 64, 6, 2, 40),
                                                 (4096, 256, 12, 4, 2500)])
 def test_in_launch_hand_overs_are_race_free(ctx, N, S, n_c, n_u, depth):
-    """The Gram reduce finishes its own columns in the last workgroup to arrive and the K <= 16 alpha kernel closes the
-    outer iteration the same way (atomics-only hand-over, no kernel boundary in between).  The sums involved are exact
-    integers or fixed-order f64 sums, so every repetition of a solve must give the SAME BITS; a missed or late
-    contribution (seen once with no-return atomics: 1e-5 relative, one run in three) shows up as a difference."""
+    """The K <= 16 alpha kernel closes the outer iteration in its last workgroup to arrive (atomics-only hand-over, no
+    kernel boundary in between); the Gram reduce did the same for its columns until round 3 and hands over to a launch of
+    its own now (k_gram_v2_finish).  The sums involved are exact integers or fixed-order f64 sums, so every repetition of
+    a solve must give the SAME BITS; a missed or late contribution (seen once with no-return atomics: 1e-5 relative, one
+    run in three) shows up as a difference."""
     from demethify_amd import _lib as L
     from demethify_amd.device import Problem, Solver
 
