@@ -40,6 +40,7 @@ SIGNATURES = {
     "dmf_context_set_stop_confirmation": (C.c_int, [_p, C.c_int]),
     "dmf_problem_create": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, C.c_int, C.POINTER(_p)]),
     "dmf_problem_gather": (C.c_int, [_p, _p, _p, _i64, C.POINTER(_p)]),
+    "dmf_problem_gather_device": (C.c_int, [_p, _p, _p, _i64, C.POINTER(_p)]),
     "dmf_problem_destroy": (C.c_int, [_p]),
     "dmf_problem_shape": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "dmf_cost": (C.c_int, [_p, _p, _p, _i64, _p, C.c_int, _dbl_p]),

@@ -87,10 +87,10 @@ def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, 
         # (deconvolution.py:41), so the draws do not depend on the order the threads run in -- but only ONE thread may
         # run initialisers at a time.  When the init does not look at the resampled data ('uniform_' and the other
         # data-free options) the two draws are independent and get a thread each; otherwise one thread does both.
-        from .staging import Prefetcher, reserve, to_device
+        from .staging import Prefetcher, indices_to_device, reserve, to_device
 
         ctx = get_context()
-        reserve(((n_rows, n_u), (n_ct + n_u, n_samples)), count=2)
+        reserve(((n_rows, n_u), (n_ct + n_u, n_samples), (n_rows,)), count=2)
 
         mine = shard.my_items(n_bootstrap, rank, world)
         needs_data = init_option == "uniform"
@@ -105,25 +105,29 @@ def bt_ci(confidence_level, n_bootstrap, n_u, meth_f, counts, ref, init_option, 
                 u0, _, a0 = init_BSSMF_md(init_option, mf, ct, rf, n_u, rb_alg=wls_intercept, seed=seeds[i], _stack=False)
             return to_device((u0, a0), ctx)  # page-locked copy + upload on the context's copy stream, here in the worker
 
-        def draw_both(i):
+        def draw_rows(i):
+            # (the row indices travel to HBM from here too: 8 MB from pageable memory took the solving thread ~1 ms per replicate)
             idx = bootstrap_row_indices(seeds[i], n_rows)
-            return (idx,) + draw_init(i, idx)
+            return idx, indices_to_device(idx, ctx)
+
+        def draw_both(i):
+            idx, idx_dev = draw_rows(i)
+            return (idx, idx_dev) + tuple(draw_init(i, idx))
 
         if needs_data:
             feeds = (Prefetcher(mine, draw_both, depth=2, workers=1),)
         else:
-            feeds = (Prefetcher(mine, lambda i: bootstrap_row_indices(seeds[i], n_rows), depth=2, workers=1),
-                     Prefetcher(mine, draw_init, depth=2, workers=1))
+            feeds = (Prefetcher(mine, draw_rows, depth=2, workers=1), Prefetcher(mine, draw_init, depth=2, workers=1))
         u_stack = _device_stack(len(mine), n_rows * n_u)  # replicate profiles stay in HBM when torch is there
         try:
             with Problem(ctx, meth_f, counts, ref) as full:
                 for j, parts in enumerate(zip(*feeds)):
                     if needs_data:
-                        (i, (idx, u0, a0)), = parts
+                        (i, (idx, idx_dev, u0, a0)), = parts
                     else:
-                        (i, idx), (i2, (u0, a0)) = parts
+                        (i, (idx, idx_dev)), (i2, (u0, a0)) = parts
                         assert i == i2
-                    with full.gather(idx) as resampled, Solver(resampled, u0, a0, L.DMF_MODE_PARTIAL) as s:
+                    with full.gather(idx_dev) as resampled, Solver(resampled, u0, a0, L.DMF_MODE_PARTIAL) as s:
                         if purity_frac is not None:
                             s.set_purity(purity_frac)
                         s.step(n_iter1, n_iter2, tol)

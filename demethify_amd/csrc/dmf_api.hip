@@ -367,8 +367,15 @@ int problem_finalize(dmf_problem* p, bool counts_done = false) {
     // kernel takes them (n_c <= 16 here: 136 + 16 jobs at most); v^T D v goes through the generic kernel alone
     const bool mfma = n_c >= 1 && ctx->generic_level != 1 && ctx->generic_level != 2;
     const int n_fast = mfma ? n_jobs - 1 : 0, n_dense = (int)(n_c * (n_c + 1) / 2);
+    // With integer copies of the counts the known block takes the solver's own integer route: the dense pairs on the integer
+    // matrix cores from the 8-bit planes (exact sums of fixed-point products), the right-hand sides sum_i Rt_ik d_is v_is
+    // from the u16 stream kernel -- 0.26 + 2.6 GB instead of the 4.5 GB of V and the f64 counts that the FP64 matrix-core
+    // kernel reads (1.5 ms at 1e6 x 256 x 12; every bootstrap replicate builds a problem).
+    const bool int_known = mfma && ctx->generic_level == 0 && p->Dt8 != nullptr && p->D16 != nullptr && p->Rtp != nullptr &&
+                           (reinterpret_cast<uintptr_t>(p->Rtp) & 15) == 0 &&
+                           dmf::gram_i8_known_supported((int)n_c, p->ND, N, p->SD);
     int64_t slab_doubles = dmf::gram_slab_doubles(N, (int)S, mfma ? 1 : n_jobs);
-    if (mfma) {
+    if (mfma && !int_known) {
         const int64_t need = dmf::gram_mfma_slab_doubles(N, (int)S, n_fast);
         if (need > slab_doubles) slab_doubles = need;
     }
@@ -381,7 +388,32 @@ int problem_finalize(dmf_problem* p, bool counts_done = false) {
     HIP_TRY(hipMemcpyAsync(dl, hl.data(), n_jobs * sizeof(short), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(dd, hd.data(), n_jobs * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     hipError_t e = hipSuccess;
-    if (mfma) {
+    bool vdv_done = true;  // (in: asked for; out: delivered)
+    if (int_known) {
+        long long *slab_i8 = nullptr, *acc = nullptr;
+        double* slab_bu = nullptr;
+        const int64_t slab_words = dmf::gram_i8_slab_words_nf(N, p->SD, n_dense);
+        const int64_t acc_words = dmf::gram_i8_acc_words_nf((int)S, n_dense, (int)n_c + 1);
+        e = pool_alloc(ctx, (void**)&slab_i8, (size_t)slab_words * sizeof(long long));
+        if (e == hipSuccess) e = pool_alloc(ctx, (void**)&acc, (size_t)acc_words * sizeof(long long));
+        if (e == hipSuccess) e = pool_alloc(ctx, (void**)&slab_bu, (size_t)dmf::bu_cols_grid(N) * (n_c + 1) * S * sizeof(double));
+        if (e == hipSuccess) e = hipMemsetAsync(acc, 0, (size_t)acc_words * sizeof(long long), ctx->stream);
+        int ny = 0, n_slabs = 0;
+        if (e == hipSuccess)
+            e = dmf::launch_gram_i8(p->Dt8, p->plane_stride, p->SD, p->ND, p->Rtp, nullptr, N, (int)n_c, 0, dk, dl, n_dense,
+                                    slab_i8, slab_words, nullptr, &ny, ctx->stream);
+        if (e == hipSuccess)  // (v^T D v rides along where the two-samples-per-lane form of the stream kernel runs)
+            e = dmf::launch_bu_cols(p->V, p->D16, p->SD, p->Rt, N, (int)S, (int)n_c, slab_bu, nullptr, &n_slabs, ctx->stream,
+                                    &vdv_done);
+        // (dd lists the dense pairs first, then the n_c right-hand sides, then (v, v): the order of the reduce's jobs)
+        if (e == hipSuccess)
+            e = dmf::launch_gram_v2_reduce(slab_i8, ny, n_dense, p->SD, slab_bu, n_slabs, (int)n_c + (vdv_done ? 1 : 0), (int)S,
+                                           acc, dd, p->gb_known, nullptr, nullptr, 0, nullptr, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        pool_free(ctx, slab_i8);
+        pool_free(ctx, acc);
+        pool_free(ctx, slab_bu);
+    } else if (mfma) {
         dmf::GramJobTable fast{dk, dl, dd, n_fast};
         int ny = 0;
         e = dmf::launch_gram_mfma(p->V, p->D, p->Rt, nullptr, N, (int)S, (int)n_c, 0, fast, n_dense, slab,
@@ -389,7 +421,9 @@ int problem_finalize(dmf_problem* p, bool counts_done = false) {
         if (e == hipSuccess)
             e = dmf::launch_gram_reduce(slab, ny, n_fast, (int)S, dd, p->gb_known, nullptr, ctx->stream);
     }
-    if (e == hipSuccess && n_jobs - n_fast == 1 && ctx->generic_level != 1 && ctx->generic_level != 2 &&
+    if (e == hipSuccess && int_known && vdv_done) {
+        // (nothing left)
+    } else if (e == hipSuccess && n_jobs - n_fast == 1 && ctx->generic_level != 1 && ctx->generic_level != 2 &&
         (int64_t)dmf::vdv_cols_grid(N) * S <= slab_doubles) {
         // what is left is v^T D v alone: a stream kernel of its own (the generic kernel took 2.7 ms for it at 1e6 x 256)
         e = dmf::launch_vdv_cols(p->V, p->D, p->D16, p->SD, N, (int)S, slab, p->gb_known + (int64_t)hd[n_jobs - 1] * S,
@@ -893,13 +927,10 @@ int dmf_problem_create(dmf_context* ctx, int64_t N, int64_t S, int64_t n_c, cons
     return DMF_OK;
 }
 
-int dmf_problem_gather(dmf_context* ctx, const dmf_problem* src, const int64_t* idx, int64_t n_idx,
-                       dmf_problem** out) {
-    DMF_TRY(check_ctx(ctx));
-    if (src == nullptr || idx == nullptr || out == nullptr || n_idx <= 0) return DMF_ERR_BAD_ARG;
-    *out = nullptr;
-    for (int64_t r = 0; r < n_idx; ++r)
-        if (idx[r] < 0 || idx[r] >= src->N) return DMF_ERR_BAD_ARG;
+// the row gather behind both entry points; idx_dev: the index array is the caller's device array (range-checked here, on the
+// device), else a host array (checked by the caller of this function; uploaded here)
+static int problem_gather(dmf_context* ctx, const dmf_problem* src, const int64_t* idx, int64_t n_idx, bool idx_dev,
+                          dmf_problem** out) {
     dmf_problem* p = new (std::nothrow) dmf_problem();
     if (p == nullptr) return DMF_ERR_BAD_ARG;
     p->ctx = ctx;
@@ -908,8 +939,24 @@ int dmf_problem_gather(dmf_context* ctx, const dmf_problem* src, const int64_t* 
     p->n_c = src->n_c;
     long long* d_idx = nullptr;
     int st = DMF_OK;
-    hipError_t e = pool_alloc(ctx, (void**)&d_idx, (size_t)n_idx * sizeof(long long));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, (size_t)n_idx * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipSuccess;
+    if (idx_dev) {
+        unsigned int* d_bad = nullptr;
+        unsigned int h_bad = 1;
+        e = pool_alloc(ctx, (void**)&d_bad, sizeof(unsigned int));
+        if (e == hipSuccess) e = dmf::launch_index_range_check(reinterpret_cast<const long long*>(idx), n_idx, src->N, d_bad, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        pool_free(ctx, d_bad);
+        if (e != hipSuccess || h_bad != 0) {
+            delete p;
+            return e != hipSuccess ? hip_fail(e, "index range check", __LINE__) : DMF_ERR_BAD_ARG;
+        }
+        d_idx = reinterpret_cast<long long*>(const_cast<int64_t*>(idx));
+    } else {
+        e = pool_alloc(ctx, (void**)&d_idx, (size_t)n_idx * sizeof(long long));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, (size_t)n_idx * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    }
     if (e == hipSuccess) e = pool_alloc(ctx, (void**)&p->V, (size_t)n_idx * p->S * sizeof(double));
     if (e == hipSuccess) p->own_V = true, e = pool_alloc(ctx, (void**)&p->D, (size_t)n_idx * p->S * sizeof(double));
     if (e == hipSuccess) p->own_D = true;
@@ -948,7 +995,7 @@ int dmf_problem_gather(dmf_context* ctx, const dmf_problem* src, const int64_t* 
         pool_free(ctx, d_max);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    pool_free(ctx, d_idx);
+    if (!idx_dev) pool_free(ctx, d_idx);
     if (e != hipSuccess) st = hip_fail(e, "row gather", __LINE__);
     if (st == DMF_OK) st = problem_finalize(p, counts_done);
     if (st != DMF_OK) {
@@ -957,6 +1004,24 @@ int dmf_problem_gather(dmf_context* ctx, const dmf_problem* src, const int64_t* 
     }
     *out = p;
     return DMF_OK;
+}
+
+int dmf_problem_gather(dmf_context* ctx, const dmf_problem* src, const int64_t* idx, int64_t n_idx,
+                       dmf_problem** out) {
+    DMF_TRY(check_ctx(ctx));
+    if (src == nullptr || idx == nullptr || out == nullptr || n_idx <= 0) return DMF_ERR_BAD_ARG;
+    *out = nullptr;
+    for (int64_t r = 0; r < n_idx; ++r)
+        if (idx[r] < 0 || idx[r] >= src->N) return DMF_ERR_BAD_ARG;
+    return problem_gather(ctx, src, idx, n_idx, false, out);
+}
+
+int dmf_problem_gather_device(dmf_context* ctx, const dmf_problem* src, const int64_t* idx_dev, int64_t n_idx,
+                              dmf_problem** out) {
+    DMF_TRY(check_ctx(ctx));
+    if (src == nullptr || idx_dev == nullptr || out == nullptr || n_idx <= 0) return DMF_ERR_BAD_ARG;
+    *out = nullptr;
+    return problem_gather(ctx, src, idx_dev, n_idx, true, out);
 }
 
 int dmf_problem_destroy(dmf_problem* p) {

@@ -81,6 +81,7 @@ hipError_t launch_sumsq_f64(const double* x, int64_t n, double* scratch, double*
                             const int* done_flag, hipStream_t st);
 hipError_t launch_pad_rows(const double* src, double* dst, int64_t n_rows, int width_src, int width_dst,
                            hipStream_t st);
+hipError_t launch_index_range_check(const long long* idx, int64_t n_idx, int64_t n_src, unsigned int* flag, hipStream_t st);
 hipError_t launch_gather_rows(const double* src, double* dst, const long long* idx, int64_t n_idx,
                               int64_t width, hipStream_t st);
 
@@ -222,6 +223,10 @@ hipError_t launch_rowpass_v2(const double* V, const unsigned short* D16, int SD,
 bool gram_i8_supported(int n_c, int n_u, int ND, int64_t N, int SD);
 int64_t gram_i8_slab_words(int64_t N, int SD, int n_c, int n_u);  // i64 words of the slab
 int64_t gram_i8_acc_words(int S, int n_c, int n_u);               // i64 words of the reduction scratch (zero-initialised)
+// the known block of the packed Gram through the same kernels (features = pairs of R_trunc columns; n_u = 0)
+bool gram_i8_known_supported(int n_c, int ND, int64_t N, int SD);
+int64_t gram_i8_slab_words_nf(int64_t N, int SD, int nf);
+int64_t gram_i8_acc_words_nf(int S, int nf, int n_bu);
 // exact cross / uu Gram entries: features p = (feat_a[p], feat_b[p]) over x = (Rt, u), i64 slab [ny][2][slots][SD];
 // Rtp = the padded R_trunc copy (rows of 4 ceil(n_c / 4) doubles); Rtp, u, Dt8 16-byte aligned, u allocated to a
 // multiple of 16 bytes
@@ -231,7 +236,7 @@ hipError_t launch_gram_i8(const signed char* Dt8, int64_t plane_stride, int SD, 
 // b_u alone (for u phases that are kernels of their own): slab [n_slabs][n_u][S] doubles, n_u <= 20
 int bu_cols_grid(int64_t N);
 hipError_t launch_bu_cols(const double* V, const unsigned short* D16, int SD, const double* u, int64_t N, int S, int n_u,
-                          double* slab, const int* done_flag, int* n_slabs_out, hipStream_t st);
+                          double* slab, const int* done_flag, int* n_slabs_out, hipStream_t st, bool* with_vdv = nullptr);
 // gb rows of the u-dependent jobs from the i64 slab (jobs < NF) and the row pass's b_u slabs (jobs NF .. NF + n_u);
 // acc_words: gram_i8_acc_words() i64 words, all zero before the first call (the kernels leave them zero again);
 // u2_partials != null: the finish kernel also sums the row pass's ||u||^2 shares into state (u_norm2, l_h)

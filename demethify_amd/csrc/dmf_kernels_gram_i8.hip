@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void k_bu_cols(const double* __restrict__ V, c
 template <int NU>
 __global__ __launch_bounds__(256) void k_bu_cols2(const double* __restrict__ V, const unsigned short* __restrict__ D16, int SD,
                                                   const double* __restrict__ u, int64_t N, int S, double* __restrict__ slab,
-                                                  const int* __restrict__ done_flag) {
+                                                  const int* __restrict__ done_flag, int with_vdv) {
     typedef double v2d __attribute__((ext_vector_type(2)));
     constexpr int kRows = 8;
     __shared__ double red[3][NU][2][64];
@@ -568,6 +568,10 @@ __global__ __launch_bounds__(256) void k_bu_cols2(const double* __restrict__ V, 
     double acc[NU][2];
 #pragma unroll
     for (int j = 0; j < NU; ++j) acc[j][0] = acc[j][1] = 0.0;
+    // with_vdv: one more slab row per workgroup, sum_i d v^2 of the same stream (the v^T D v entry of a problem's known
+    // block: problem_finalize) -- two more FMAs per row pair on a kernel that waits for HBM
+    double vdv0 = 0.0, vdv1 = 0.0;
+    const int ncol = NU + (with_vdv ? 1 : 0);
     const int64_t stride = (int64_t)gridDim.x * 4;
     for (int64_t i0 = (int64_t)blockIdx.x * 4 + wave; i0 < N; i0 += kRows * stride) {
         double t0[kRows], t1[kRows];
@@ -580,6 +584,8 @@ __global__ __launch_bounds__(256) void k_bu_cols2(const double* __restrict__ V, 
             const v2d_u v = *reinterpret_cast<const v2d_u*>(V + row[x] * S + sc);
             t0[x] = (double)(dd & 0xFFFFu) * (lone ? v.y : v.x);
             t1[x] = (double)(dd >> 16) * v.y;
+            vdv0 = fma(t0[x], lone ? v.y : v.x, vdv0);
+            vdv1 = fma(t1[x], v.y, vdv1);
         }
 #pragma unroll
         for (int x = 0; x < kRows; ++x) {
@@ -603,9 +609,22 @@ __global__ __launch_bounds__(256) void k_bu_cols2(const double* __restrict__ V, 
     if (wave == 0 && active) {
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
-            double* __restrict__ out = slab + ((int64_t)blockIdx.x * NU + j) * S + s;
+            double* __restrict__ out = slab + ((int64_t)blockIdx.x * ncol + j) * S + s;
             out[0] = ((acc[j][0] + red[0][j][0][lane]) + red[1][j][0][lane]) + red[2][j][0][lane];
             if (!lone) out[1] = ((acc[j][1] + red[0][j][1][lane]) + red[1][j][1][lane]) + red[2][j][1][lane];
+        }
+    }
+    if (with_vdv) {  // (wave-uniform; the cross-wave buffer is free again behind a second barrier)
+        __syncthreads();
+        if (wave > 0) {
+            red[wave - 1][0][0][lane] = vdv0;
+            red[wave - 1][0][1][lane] = vdv1;
+        }
+        __syncthreads();
+        if (wave == 0 && active) {
+            double* __restrict__ out = slab + ((int64_t)blockIdx.x * ncol + NU) * S + s;
+            out[0] = ((vdv0 + red[0][0][0][lane]) + red[1][0][0][lane]) + red[2][0][0][lane];
+            if (!lone) out[1] = ((vdv1 + red[0][0][1][lane]) + red[1][0][1][lane]) + red[2][0][1][lane];
         }
     }
 }
@@ -616,16 +635,21 @@ int bu_cols_grid(int64_t N) {
     return (int)(want < 1 ? 1 : want);
 }
 
+// with_vdv (may be null): in: the caller would like sum_i d v^2 as one more slab row per workgroup (slab rows n_u + 1);
+// out: whether the kernel chosen for this shape delivers it.
 hipError_t launch_bu_cols(const double* V, const unsigned short* D16, int SD, const double* u, int64_t N, int S, int n_u,
-                          double* slab, const int* done_flag, int* n_slabs_out, hipStream_t st) {
+                          double* slab, const int* done_flag, int* n_slabs_out, hipStream_t st, bool* with_vdv) {
     const int nbx = bu_cols_grid(N);
     *n_slabs_out = nbx;
     const dim3 block(256);
-    if ((SD & 1) == 0 && S >= 128 && n_u <= 16 && (reinterpret_cast<uintptr_t>(V) & 7) == 0) {
+    const bool two = (SD & 1) == 0 && S >= 128 && n_u <= 16 && (reinterpret_cast<uintptr_t>(V) & 7) == 0;
+    const int vdv = (with_vdv != nullptr && *with_vdv && two) ? 1 : 0;
+    if (with_vdv != nullptr) *with_vdv = vdv != 0;
+    if (two) {
         const dim3 grid2(nbx, (S + 127) / 128);
         switch (n_u) {  // (LDS for the cross-wave sum: 3 x NU x 2 x 64 doubles = 48 KB at sixteen unknowns)
 #define DMF_CASE2(NU_) \
-    case NU_: hipLaunchKernelGGL((k_bu_cols2<NU_>), grid2, block, 0, st, V, D16, SD, u, N, S, slab, done_flag); return hipGetLastError();
+    case NU_: hipLaunchKernelGGL((k_bu_cols2<NU_>), grid2, block, 0, st, V, D16, SD, u, N, S, slab, done_flag, vdv); return hipGetLastError();
             DMF_CASE2(1) DMF_CASE2(2) DMF_CASE2(3) DMF_CASE2(4) DMF_CASE2(5) DMF_CASE2(6) DMF_CASE2(7) DMF_CASE2(8) DMF_CASE2(9) DMF_CASE2(10)
             DMF_CASE2(11) DMF_CASE2(12) DMF_CASE2(13) DMF_CASE2(14) DMF_CASE2(15) DMF_CASE2(16)
 #undef DMF_CASE2
@@ -786,6 +810,25 @@ bool gram_i8_supported(int n_c, int n_u, int ND, int64_t N, int SD) {
     gram_i8_geometry(N, SD, &nsh, &ny, &rpw);
     return rpw * 128 * 128 * ND < (int64_t)1 << 31;  // i32 accumulators cannot overflow within a row range
 }
+
+// The known block of a problem's packed Gram (dmf_api.hip, problem_finalize) through the same kernels: its dense pairs
+// (R_trunc column k x column l) are features whose two factors both come from the R_trunc image (n_u = 0), its
+// right-hand sides sum_i Rt_ik d_is v_is are k_bu_cols with R_trunc in the place of u.
+bool gram_i8_known_supported(int n_c, int ND, int64_t N, int SD) {
+    const int nf = n_c * (n_c + 1) / 2;
+    if (n_c < 1 || (n_c + 3) / 4 * 4 > 32 || nf > kMaxFeat || ND < 1 || ND > 2) return false;
+    int nsh, ny;
+    int64_t rpw;
+    gram_i8_geometry(N, SD, &nsh, &ny, &rpw);
+    return rpw * 128 * 128 * ND < (int64_t)1 << 31;
+}
+int64_t gram_i8_slab_words_nf(int64_t N, int SD, int nf) {
+    int nsh, ny;
+    int64_t rpw;
+    gram_i8_geometry(N, SD, &nsh, &ny, &rpw);
+    return (int64_t)ny * 2 * ((nf + 31) / 32 * 32) * SD;
+}
+int64_t gram_i8_acc_words_nf(int S, int nf, int n_bu) { return (int64_t)2 * nf * S + (int64_t)kRedChunks * n_bu * S; }
 
 // i64 words: [ny][2][slots][SD] slab + acc64[2][nf][S] + (as doubles) bu_part[kRedChunks][n_u][S]
 int64_t gram_i8_slab_words(int64_t N, int SD, int n_c, int n_u) {

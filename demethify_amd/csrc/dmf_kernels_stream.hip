@@ -126,6 +126,26 @@ hipError_t launch_gather_rows(const double* src, double* dst, const long long* i
     return hipGetLastError();
 }
 
+// flag |= 1 if any idx[r] lies outside [0, n_src) (dmf_problem_gather_device: the range check of a device index array)
+__global__ __launch_bounds__(256) void k_index_range_check(const long long* __restrict__ idx, int64_t n_idx, int64_t n_src,
+                                                           unsigned int* __restrict__ flag) {
+    bool bad = false;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_idx; r += (int64_t)gridDim.x * 256) {
+        const long long v = idx[r];
+        bad = bad || v < 0 || v >= n_src;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+hipError_t launch_index_range_check(const long long* idx, int64_t n_idx, int64_t n_src, unsigned int* flag, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(unsigned int), st);
+    if (e != hipSuccess) return e;
+    int64_t b = (n_idx + 255) / 256;
+    if (b > 1024) b = 1024;
+    hipLaunchKernelGGL(k_index_range_check, dim3((unsigned)(b < 1 ? 1 : b)), dim3(256), 0, st, idx, n_idx, n_src, flag);
+    return hipGetLastError();
+}
+
 // dst[r][0..width_dst) = src[r][0..width_src) followed by zeros (row-padded copy of R_trunc)
 __global__ __launch_bounds__(256) void k_pad_rows(const double* __restrict__ src, double* __restrict__ dst,
                                                   int64_t n_rows, int width_src, int width_dst) {
@@ -384,7 +404,14 @@ __global__ __launch_bounds__(64) void k_vdv_finish(const double* __restrict__ sl
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= S) return;
     double acc = 0.0;
-    for (int b = 0; b < nb; ++b) acc += slab[(int64_t)b * S + s];
+    for (int b = 0; b < nb; b += 8) {  // (eight loads in flight, the same order of additions: 256 round trips were 0.1 ms)
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = slab[(int64_t)(b + q < nb ? b + q : b) * S + s];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (b + q < nb) acc += v[q];
+    }
     out[s] = acc;
 }
 

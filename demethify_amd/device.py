@@ -197,9 +197,15 @@ class Problem:
         return self
 
     def gather(self, idx) -> "Problem":
-        """Row-resampled copy (one bootstrap replicate, bootstrap.py:28)."""
-        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        """Row-resampled copy (one bootstrap replicate, bootstrap.py:28).  idx: a host integer array, or the int64 indices
+        already in HBM (staging.indices_to_device: uploaded by the thread that drew them)."""
         h = C.c_void_p()
+        if getattr(idx, "is_cuda", False):
+            n = int(np.prod(idx.shape))
+            L.check(self._lib.dmf_problem_gather_device(self.ctx._h, self._h, C.c_void_p(idx.data_ptr()), n, C.byref(h)),
+                    "dmf_problem_gather_device")
+            return Problem._from_handle(self.ctx, h, n, self.S, self.n_c)
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
         L.check(self._lib.dmf_problem_gather(self.ctx._h, self._h, _ptr(idx), idx.size, C.byref(h)),
                 "dmf_problem_gather")
         return Problem._from_handle(self.ctx, h, int(idx.size), self.S, self.n_c)

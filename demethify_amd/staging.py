@@ -128,6 +128,25 @@ def to_device(arrays, ctx):
     return out
 
 
+def indices_to_device(idx, ctx):
+    """Upload an int64 index array (a bootstrap replicate's row draw) the same way: page-locked copy, dmf_stage_upload.
+    The DeviceArray's bytes are the int64 values (Problem.gather takes it in place of the host array)."""
+    import ctypes as C
+
+    from . import _lib as L
+
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    buf = _borrow(idx.shape)  # (float64 staging buffers: the same eight bytes per element)
+    try:
+        np.copyto(buf.view(np.int64), idx)
+        dev = C.c_void_p()
+        L.check(ctx._lib.dmf_stage_upload(ctx._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes, C.byref(dev)),
+                "dmf_stage_upload")
+    finally:
+        _give_back(buf)
+    return DeviceArray(ctx, dev.value, idx.shape)
+
+
 def reserve(shapes, count: int = 1):
     """Page-lock ``count`` staging buffers per shape now (a restart job does this once, before its first restart,
     instead of inside the first uploads)."""

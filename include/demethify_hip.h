@@ -116,6 +116,10 @@ int dmf_problem_create(dmf_context* ctx, int64_t N, int64_t S, int64_t n_c,
  * (bootstrap.py:28, sklearn.utils.resample applied to the three arrays).  idx: host int64. */
 int dmf_problem_gather(dmf_context* ctx, const dmf_problem* src, const int64_t* idx,
                        int64_t n_idx, dmf_problem** out);
+/* The same with the row indices already in HBM (e.g. uploaded by dmf_stage_upload from the thread that drew them, beside
+ * the previous replicate's solve): range-checked on the device, DMF_ERR_BAD_ARG when one lies outside [0, N). */
+int dmf_problem_gather_device(dmf_context* ctx, const dmf_problem* src, const int64_t* idx_dev,
+                              int64_t n_idx, dmf_problem** out);
 int dmf_problem_destroy(dmf_problem* p);
 int dmf_problem_shape(const dmf_problem* p, int64_t* N, int64_t* S, int64_t* n_c);
 

@@ -158,6 +158,12 @@ def test_gather_rows_matches_fancy_indexing(ctx):
         got = q.cost(u, alpha)
     want = osol.weighted_cost(V[idx], np.c_[Rt[idx], u], alpha, D[idx])
     assert abs(got - want) <= 1e-11 * want
+    # the same resample from row indices that are already in HBM (what the bootstrap driver's worker thread uploads)
+    from demethify_amd.staging import indices_to_device
+
+    with Problem(ctx, V, D, Rt) as p, p.gather(indices_to_device(idx, ctx)) as q:
+        assert q.N == idx.size
+        assert q.cost(u, alpha) == got
 
 
 def test_bad_arguments_raise(ctx):
@@ -174,6 +180,13 @@ def test_bad_arguments_raise(ctx):
             Solver(p, u, alpha[:-1])
         with pytest.raises(DemethifyHipError):
             p.gather(np.array([0, 100]))
+        from demethify_amd.staging import indices_to_device
+
+        for bad in ([0, 100], [-1, 5], [3, 1 << 40]):  # (range-checked on the device before any row is read)
+            with pytest.raises(DemethifyHipError):
+                p.gather(indices_to_device(np.array(bad), ctx))
+        with p.gather(indices_to_device(np.array([99, 0, 99]), ctx)) as q:
+            assert q.N == 3
 
 
 @pytest.mark.parametrize("n,m,q", [

@@ -8,6 +8,7 @@ import bench
 from demethify_amd import _lib as L
 from demethify_amd.device import Context, Problem, Solver
 from demethify_amd.bootstrap import bootstrap_row_indices
+from demethify_amd.staging import indices_to_device
 
 N, S, n_c, n_u = bench.WORKLOADS["headline_1e6x256_12+4"]
 dev = torch.device("cuda", 0)
@@ -21,11 +22,12 @@ def T(f):
 for rep in range(4):
     idx, t_idx = T(lambda: bootstrap_row_indices(rep + 1, N))
     (u0, a0), t_init = T(lambda: bench.restart_init(rep, N, S, n_c, n_u))
-    res, t_gather = T(lambda: full.gather(idx))
+    idx_dev, t_up = T(lambda: indices_to_device(idx, ctx))  # (what the driver's worker thread does, beside the previous solve)
+    res, t_gather = T(lambda: full.gather(idx_dev))
     s, t_create = T(lambda: Solver(res, u0, a0, L.DMF_MODE_PARTIAL))
     _, t_step = T(lambda: s.step(20, 20, 0.0))
     _, t_copy = T(lambda: s.copy_u_to(stack[rep]))
     _, t_alpha = T(lambda: s.get_alpha())
     _, t_close = T(lambda: (s.close(), res.close()))
-    print(f"rep {rep}: host row draw {t_idx:.1f} ms, host init {t_init:.1f} | gather + problem set-up {t_gather:.1f} | solver create (host u0) {t_create:.1f} | "
+    print(f"rep {rep}: host row draw {t_idx:.1f} ms, host init {t_init:.1f}, index upload {t_up:.1f} | gather + problem set-up {t_gather:.1f} | solver create (host u0) {t_create:.1f} | "
           f"20 iterations {t_step:.1f} | copy u to the stack {t_copy:.2f} | alpha to host {t_alpha:.2f} | close {t_close:.2f}")
