@@ -12,7 +12,7 @@
 //
 // Per 16-row block, per workgroup (waves = column groups):
 //   tile    prefetched global loads (V: 16 B per lane, two rows per instruction; D16: 16 B = 8 counts per lane)
-//           -> LDS tile of the wave's own column group (V f64, D as f32: exact for counts < 2^24)
+//           -> LDS tile of the wave's own column group (V f64, the counts as the u16 they arrive as)
 //   phase A FP64-MFMA contractions on the tile in the row-on-lane layout (as dmf_kernels_rowpass_mfma.hip):
 //           E = V - Rt a_known (16x16x4), c = a_unk (D*E)^T (4x4x4, 4 blocks); M = D P^T exactly on the i8 MFMA
 //           (16x16x64, counts and P = alpha_j alpha_l as balanced 8-bit digits) -> partial c / M
@@ -36,7 +36,6 @@ namespace dmf {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -70,11 +69,10 @@ __device__ __forceinline__ unsigned long long dmf2_stamp() {
 
 namespace {
 constexpr int kRowV = 66;  // V tile row: 64 samples + 16 B pad (f64)
-constexpr int kRowD = 68;  // D tile row: 64 samples + 16 B pad (f32)
-constexpr int kRowB = 80;  // count-digit tile row: 64 samples (1 byte each) + 16 B pad
+constexpr int kRowD = 72;  // count tile row: 64 samples as u16 + 16 B pad (36 dwords: rows 4, 8, 12 apart start 16, 32, 48 banks apart)
 constexpr int kTileVBytes2 = 16 * kRowV * 8;
-constexpr int kTileDBytes2 = 16 * kRowD * 4;
-constexpr int kTileBytes2 = kTileVBytes2 + kTileDBytes2 + 2 * 16 * kRowB;  // one column group: V, D (f32), 2 digit planes
+constexpr int kTileDBytes2 = 16 * kRowD * 2;
+constexpr int kTileBytes2 = kTileVBytes2 + kTileDBytes2;  // one column group: V (f64), counts (u16, as they arrive)
 }  // namespace
 
 // One accelerated projected-gradient step of a row group (deconvolution.py:83-88): (cur, prev) = (u, u_) in,
@@ -152,7 +150,7 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
     const int wcol0 = wave * 64;
 
     // LDS carve-up (doubles unless noted): beta[n_iter2 (even)] | ubuf[16][NU] | red[MAXW][16][NU][SLOT] | u2[MAXW] |
-    //   tiles[NW]{ V f64 [16][66], D f32 [16][68], count digits [2][16][80] }
+    //   tiles[NW]{ V f64 [16][66], counts u16 [16][72] }
     double* __restrict__ beta_tab = lds_dyn;
     double* __restrict__ ubuf = beta_tab + ((n_iter2 + 1) & ~1);
     double* __restrict__ red = ubuf + 16 * NU;
@@ -160,8 +158,10 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
     char* __restrict__ tile0 = reinterpret_cast<char*>(u2red + MAXW);
     char* __restrict__ tile = tile0 + (size_t)wave * kTileBytes2;
     double* __restrict__ tileV = reinterpret_cast<double*>(tile);
-    float* __restrict__ tileD = reinterpret_cast<float*>(tile + kTileVBytes2);
-    char* __restrict__ tileB = tile + kTileVBytes2 + kTileDBytes2;  // [2 digit planes][16][kRowB]: counts as balanced bytes
+    // the counts stay u16 in the tile (LINEAR rows: no piece swap): phase A and phase C convert what they read, the integer
+    // product builds its balanced byte digits from 32 bytes of a row -- converting at the tile store (f32 copy + two digit
+    // planes: 52 vector instructions and 8 LDS writes per block and wave, on every wave's critical path) cost 9 % of the kernel
+    unsigned short* __restrict__ tileD = reinterpret_cast<unsigned short*>(tile + kTileVBytes2);
 
     // momentum coefficients of the inner steps (deconvolution.py:83-85): from the host's row of ratios when there is one
     // (SolverState), else the recurrence itself by one thread -- n_iter2 square roots and divisions in a row, ~5 us
@@ -195,8 +195,9 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
     // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, and the same + 32): with lane = (row m16, sample piece q) a group holds
     // rows 0-3 / 12-15 at piece q0 and rows 4-11 at piece q0 + 1 (or the other way round), and in any LINEAR layout two of
     // those 16 lanes share a bank.  So rows 4..11 of every tile keep their 16-byte pieces pairwise swapped (a sample s of
-    // such a row sits where s ^ 4 would: V and the f32 counts; where s ^ 16 would: the byte planes) -- then each group
-    // reads 16 different rows at one piece offset, and the odd piece strides (33, 17, 5) make that conflict-free.
+    // such a row sits where s ^ 4 would; V only: the u16 counts are read in 8-byte and 2-byte pieces, which a linear row with a
+    // 36-dword stride serves without conflicts) -- then each group
+    // reads 16 different rows at one piece offset, and the odd piece stride (33) makes that conflict-free.
     const int sw_row = (m16 >= 4 && m16 < 12) ? 1 : 0;  // is row m16 a swapped row (phase A: lane = (row, piece))
     const int qs = q ^ sw_row;                           // where this lane's piece q sits in row m16
     // Phase C reads with lane = (row quad member q, sample m16): rows R + 8 (q & 1) + 4 (q >> 1), R = 0..3, so that the two
@@ -271,10 +272,8 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
     const int last_pair = (S - 1) & ~1;
     if (ld_gcol > last_pair) ld_gcol = last_pair;
     const int d_row = lane >> 3, d_col = (lane & 7) * 8;
-    // (tile swizzle at the stores: V rows 2 i, 2 i + 1 are swapped rows for i = 2..5; the counts' rows 8 i + d_row for
-    // d_row >= 4 at i = 0 and d_row < 4 at i = 1)
+    // (tile swizzle at the stores: V rows 2 i, 2 i + 1 are swapped rows for i = 2..5)
     const int ld_col_sw = ((lane & 31) ^ 2) * 2;
-    const int d_sw0 = d_row >= 4 ? 1 : 0;
     v2d pv[8];
     v4u pd[2];
     double nrt[NKC > 0 ? NKC : 1];
@@ -351,20 +350,7 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
             *reinterpret_cast<v2d*>(tileV + (2 * i + ld_row) * kRowV + ((i >= 2 && i < 6) ? ld_col_sw : ld_col)) = pv[i];
 #ifndef DMF_ABLATE_DSTORE
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int dsw = i == 0 ? d_sw0 : 1 - d_sw0;  // a swapped row: its two 16-byte pieces change places
-            float* __restrict__ dst = tileD + (8 * i + d_row) * kRowD + d_col;
-            const v4u w = pd[i];
-            *reinterpret_cast<v4f*>(dst + 4 * dsw) = v4f{(float)(w.x & 0xFFFFu), (float)(w.x >> 16), (float)(w.y & 0xFFFFu), (float)(w.y >> 16)};
-            *reinterpret_cast<v4f*>(dst + 4 - 4 * dsw) = v4f{(float)(w.z & 0xFFFFu), (float)(w.z >> 16), (float)(w.w & 0xFFFFu), (float)(w.w >> 16)};
-            // the same counts as balanced digits: d + 128 = b0 + 256 b1, digit 0 = b0 - 128 (b0 ^ 0x80 as i8), digit 1 = b1
-            const unsigned int e0 = w.x + 0x00800080u, e1 = w.y + 0x00800080u, e2 = w.z + 0x00800080u, e3 = w.w + 0x00800080u;
-            char* __restrict__ bdst = tileB + (8 * i + d_row) * kRowB + (d_col ^ (16 * dsw));
-            *reinterpret_cast<v2u*>(bdst) = v2u{__builtin_amdgcn_perm(e1, e0, 0x06040200u) ^ 0x80808080u,
-                                                __builtin_amdgcn_perm(e3, e2, 0x06040200u) ^ 0x80808080u};
-            *reinterpret_cast<v2u*>(bdst + 16 * kRowB) = v2u{__builtin_amdgcn_perm(e1, e0, 0x07050301u),
-                                                             __builtin_amdgcn_perm(e3, e2, 0x07050301u)};
-        }
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<v4u*>(tileD + (8 * i + d_row) * kRowD + d_col) = pd[i];
 #endif
         double rtop[NKC > 0 ? NKC : 1];
 #pragma unroll
@@ -383,19 +369,19 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
         // stalls behind its producer)
         struct Strip {
             v2d v01, v23;
-            v4f df;
+            v2u dw;  // the four counts of the piece, u16
         };
         auto load_strip = [&](int t, Strip& R) {
             const double* __restrict__ tv = tileV + m16 * kRowV + t * 16 + 4 * qs;
             R.v01 = *reinterpret_cast<const v2d*>(tv);
             R.v23 = *reinterpret_cast<const v2d*>(tv + 2);
-            R.df = *reinterpret_cast<const v4f*>(tileD + m16 * kRowD + t * 16 + 4 * qs);
+            R.dw = *reinterpret_cast<const v2u*>(tileD + m16 * kRowD + t * 16 + 4 * q);
         };
         double csm0 = 0.0, csm1 = 0.0;  // c[unknown q][row m16], one double per lane
         auto e_init = [&](const Strip& R) { return v4d{R.v01.x, R.v01.y, R.v23.x, R.v23.y}; };
         auto run_strip = [&](const Strip& R, v4d e, const Strip& Rn, const double (&a1n)[NKC > 0 ? NKC : 1],
                              const double (&a2)[4], bool has_next) {
-            const v4d d = {(double)R.df.x, (double)R.df.y, (double)R.df.z, (double)R.df.w};
+            const v4d d = {(double)(R.dw.x & 0xFFFFu), (double)(R.dw.x >> 16), (double)(R.dw.y & 0xFFFFu), (double)(R.dw.y >> 16)};
             const v4d w = d * e;
             v4d en = e_init(Rn);
 #pragma unroll
@@ -432,11 +418,21 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
         for (int w8 = 0; w8 < 8; ++w8) mw[w8] = v4i{0, 0, 0, 0};
 #ifndef DMF_ABLATE_M  // (diagnostic builds of tools/rowpass2_probe.hip leave pieces out to see what they cost)
         {
-            const v4i c0 = *reinterpret_cast<const v4i*>(tileB + m16 * kRowB + 16 * qs);  // A: counts [row m16][16 samples]
+            // A: counts [row m16][samples 16 q .. 16 q + 15] as balanced digits: d + 128 = b0 + 256 b1, digit 0 = b0 - 128
+            // (b0 ^ 0x80 as i8), digit 1 = b1
+            const v4u wa = *reinterpret_cast<const v4u*>(tileD + m16 * kRowD + 16 * q);
+            const v4u wb = *reinterpret_cast<const v4u*>(tileD + m16 * kRowD + 16 * q + 8);
+            const unsigned int e0 = wa.x + 0x00800080u, e1 = wa.y + 0x00800080u, e2 = wa.z + 0x00800080u, e3 = wa.w + 0x00800080u;
+            const unsigned int e4 = wb.x + 0x00800080u, e5 = wb.y + 0x00800080u, e6 = wb.z + 0x00800080u, e7 = wb.w + 0x00800080u;
+            const v4i c0 = {(int)(__builtin_amdgcn_perm(e1, e0, 0x06040200u) ^ 0x80808080u),
+                            (int)(__builtin_amdgcn_perm(e3, e2, 0x06040200u) ^ 0x80808080u),
+                            (int)(__builtin_amdgcn_perm(e5, e4, 0x06040200u) ^ 0x80808080u),
+                            (int)(__builtin_amdgcn_perm(e7, e6, 0x06040200u) ^ 0x80808080u)};
 #pragma unroll
             for (int t = 0; t < 7; ++t) mw[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(c0, pdg[t], mw[t], 0, 0, 0);
             if (nd == 2) {
-                const v4i c1 = *reinterpret_cast<const v4i*>(tileB + (16 + m16) * kRowB + 16 * qs);
+                const v4i c1 = {(int)__builtin_amdgcn_perm(e1, e0, 0x07050301u), (int)__builtin_amdgcn_perm(e3, e2, 0x07050301u),
+                                (int)__builtin_amdgcn_perm(e5, e4, 0x07050301u), (int)__builtin_amdgcn_perm(e7, e6, 0x07050301u)};
 #pragma unroll
                 for (int t = 0; t < 7; ++t) mw[t + 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(c1, pdg[t], mw[t + 1], 0, 0, 0);
             }
@@ -563,14 +559,14 @@ __global__ __launch_bounds__(64 * MAXW, MAXW == 4 ? 2 : 1) void k_rowpass_v2(
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             double vv[2][4], ua[2];
-            float dd[2][4];
+            unsigned short dd[2][4];
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int row = 2 * half + rr + c_row;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     vv[rr][t] = tileV[row * kRowV + 16 * t + mC];
-                    dd[rr][t] = tileD[row * kRowD + 16 * t + mC];
+                    dd[rr][t] = tileD[row * kRowD + 16 * t + m16];
                 }
                 ua[rr] = (m16 & 3) < NU ? ubuf[row * NU + (m16 & 3)] : 0.0;
             }
