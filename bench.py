@@ -212,9 +212,13 @@ def main():
             shard.allreduce_min_vector({rank: 0.0}, world)
             shard.broadcast_winner(s if rank == 0 else None, (N, n_u), (K, S), 0)
     ctx.synchronize()
-    # HIP events around the two families that stream V / D (the roofline kernel is one of them), on the stream
-    # the kernels are launched on; the KB-sized alpha phase is timed after the job
-    ctx.set_profiling(True, families=(L.KERNEL_ROWPASS, L.KERNEL_GRAM, L.KERNEL_COST))
+    # HIP events, on the stream the kernels are launched on, around EVERY launch of the roofline kernel's family (the row
+    # pass) and, during ONE restart in the middle of the timed region, around the other two families that stream V / D (the
+    # region's first restarts run while the clocks still ramp: their Gram launches take 0.17 ms against 0.145 later): an event
+    # record between two kernels leaves the GPU idle for a few microseconds, which long kernels hide (the command processor
+    # works ahead) and short ones do not -- four records per outer iteration were 13 % of config 2's 85 us iteration.  The
+    # KB-sized alpha phase is timed after the job.
+    ctx.set_profiling(True, families=(L.KERNEL_ROWPASS,))
     ctx.reset_kernel_time()
 
     mine = shard.my_items(R, rank, world)
@@ -240,15 +244,20 @@ def main():
             s.close()
 
     waiting = None
+    sampled = mine[len(mine) // 2] if len(mine) else None  # the restart whose Gram and cost launches are timed as well
     for k, (u0, a0) in feeder:
         s = Solver(problem, u0, a0, L.DMF_MODE_PARTIAL)  # (set up while the GPU takes the previous restart's cost)
         if waiting is not None:
             settle(*waiting)
+        if k == sampled:
+            ctx.set_profiling(True, families=(L.KERNEL_ROWPASS, L.KERNEL_GRAM, L.KERNEL_COST))
         tl = time.perf_counter()
         it, _ = s.step(args.steps, T2, 0.0)  # returns after the last iteration's state has been read back
         loop_s += time.perf_counter() - tl
         iters_total += it
         s.cost_begin()
+        if k == sampled:
+            ctx.set_profiling(True, families=(L.KERNEL_ROWPASS,))
         waiting = (k, s)
     if waiting is not None:
         settle(*waiting)
@@ -278,7 +287,7 @@ def main():
     ctx.set_profiling(True, families=(L.KERNEL_ALPHA,))
     u0, a0 = restart_init(rank, N, S, n_c, n_u)
     with Solver(problem, u0, a0, L.DMF_MODE_PARTIAL) as s:
-        s.step(2, T2, 0.0)  # untimed: fills in the small family of the per-family table
+        s.step(args.steps, T2, 0.0)  # untimed: fills in the small family of the per-family table
     ctx.synchronize()
     fam[L.KERNEL_FAMILIES[L.KERNEL_ALPHA]] = ctx.kernel_time(L.KERNEL_ALPHA)
     ctx.set_profiling(False)
@@ -386,6 +395,7 @@ def main():
                                     # iteration would have to stream without the integer re-encoding; NOT bytes moved
                                     "sec8d_f64_layout_bytes": b_alg, "sec8d_f64_layout_equivalent": b_alg * loop_rate / 1e9},
                 "family_avg_ms": {k: round(v[0], 4) for k, v in fam_ms.items()},
+                "family_timed": "HIP events inside the timed region: rowpass every launch, gram and cost one restart's (the middle one); alpha: one restart's launches after it",
                 "family_launches": {k: v[1] for k, v in fam_ms.items()},
             },
         }
